@@ -1,0 +1,291 @@
+"""Generate the golden fixtures under ``tests/golden/`` by running the *reference* on seeded inputs.
+
+Runs only in the build container (needs ``/root/reference``); the GPU box uses the committed
+``.npz`` files.  Every fixture stores its inputs (as float32 arrays of values exactly representable
+in the nominal dtype) and the reference's outputs, so tests can replay them against the oracle and
+against the HIP path without the reference present.
+
+    python oracle/make_golden.py            # rewrites tests/golden/*.npz
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_loader import load_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+TORCH_DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+# name -> (quantizer kwargs in plain python, input shape)
+FAKE_QUANT_CASES = {
+    # Llama W4 g128 configs (examples/llm/configs/gptq.yaml, awq.yaml)
+    "sint4_g128_f16s": dict(dtype="sint4", zero=None, groups=((1, 128),), sdt=("f16",), shape=(64, 512)),
+    "uint4_post_g128_f16s": dict(dtype="uint4", zero="PostScale", groups=((1, 128),), sdt=("f16",), shape=(64, 512)),
+    "uint4_pre_g128_f16s": dict(dtype="uint4", zero="PreScale", groups=((1, 128),), sdt=("f16",), shape=(64, 512)),
+    "sint4_pre_g128_defs": dict(dtype="sint4", zero="PreScale", groups=((1, 128),), sdt=(None,), shape=(32, 256)),
+    # SVDQuant int4 g64 (examples/diffusion/configs/svdquant/int4.yaml)
+    "sint4_g64_defs": dict(dtype="sint4", zero=None, groups=((1, 64),), sdt=(None,), shape=(48, 384)),
+    # W8A8 per-channel / per-tensor
+    "sint8_gchn_f16s": dict(dtype="sint8", zero=None, groups=((1, -1),), sdt=("f16",), shape=(64, 512)),
+    "sint8_tnsr_f16s": dict(dtype="sint8", zero=None, groups=((-1, -1),), sdt=("f16",), shape=(32, 256)),
+    "uint8_post_gchn_defs": dict(dtype="uint8", zero="PostScale", groups=((1, -1),), sdt=(None,), shape=(32, 320)),
+    # NVFP4 (examples/diffusion/configs/svdquant/nvfp4.yaml): two-level scale, fp8 group scale
+    "nvfp4_g16": dict(dtype="sfp4_e2m1_all", zero=None, groups=((-1, -1), (1, 16)), sdt=(None, "sfp8_e4m3_nan"),
+                      shape=(32, 256)),
+    "sfp4_g32_f16s": dict(dtype="sfp4_e2m1_all", zero=None, groups=((1, 32),), sdt=("f16",), shape=(32, 256)),
+    "sfp8_e4m3_gchn": dict(dtype="sfp8_e4m3_nan", zero=None, groups=((1, -1),), sdt=("f16",), shape=(16, 256)),
+    # two-level integer scales: per-channel f16 then g32 int8 scale inside one step
+    "sint4_gchn_g32_s8": dict(dtype="sint4", zero=None, groups=((1, -1), (1, 32)), sdt=("f16", "sint8"),
+                              shape=(32, 256)),
+    # QoQ W4A8 (examples/llm/configs/qoq-g128.yaml): progressive sint8 per-channel -> uint4 g128, int8 scales
+    "qoq_g128": dict(dtype="uint4", zero="PostScale", groups=((1, -1), (1, 128)), sdt=("f16", "sint8"),
+                     inter=("sint8",), levels=(0,), shape=(64, 512)),
+    "qoq_g128_pre": dict(dtype="uint4", zero="PreScale", groups=((1, -1), (1, 128)), sdt=("f16", "sint8"),
+                         inter=("sint8",), levels=(0,), shape=(32, 256)),
+    # QoQ per-channel (qoq-gchn.yaml): plain sint4 per-channel
+    "sint4_gchn_f16s": dict(dtype="sint4", zero=None, groups=((1, -1),), sdt=("f16",), shape=(64, 512)),
+    # odd group geometry: 2-row groups, and a 4-D (conv-like) weight
+    "sint4_2x64": dict(dtype="sint4", zero=None, groups=((2, 64),), sdt=("f16",), shape=(32, 256)),
+    "uint4_post_conv": dict(dtype="uint4", zero="PostScale", groups=((1, 16, -1),), sdt=("f16",), shape=(16, 64, 3, 3)),
+}
+DYN_CASES = {
+    # (case, dynamic range spec)
+    "sint4_g128_f16s@ratio0.9": ("sint4_g128_f16s", dict(ratio=0.9)),
+    "uint4_post_g128_f16s@ratio0.85": ("uint4_post_g128_f16s", dict(ratio=0.85)),
+    "uint4_pre_g128_f16s@ratio0.7": ("uint4_pre_g128_f16s", dict(ratio=0.7)),
+}
+
+
+def _mk_input(shape, dt: str, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(*shape, generator=g)
+    # heavy tail on 0.5 % of the entries so clipping matters, plus one all-zero group and one constant row
+    mask = torch.rand(*shape, generator=g) < 0.005
+    w = torch.where(mask, w * 6, w) * 0.02
+    flat = w.view(shape[0], -1)
+    flat[0, : min(128, flat.shape[1])] = 0
+    if shape[0] > 1:
+        flat[1] = 0.0123
+    return w.to(TORCH_DT[dt])
+
+
+def _build_quantizer(ref, case, default_dtype=None):
+    from deepcompressor.data.dtype import QuantDataType
+    from deepcompressor.data.zero import ZeroPointDomain
+    from deepcompressor.quantizer import Quantizer
+    from deepcompressor.quantizer.config.base import ProgressiveQuantizerConfig, QuantizerConfig
+
+    def sd(x):
+        if x is None:
+            return None
+        return TORCH_DT[x] if x in TORCH_DT else QuantDataType.from_str(x)
+
+    kw = dict(
+        dtype=QuantDataType.from_str(case["dtype"]),
+        zero_point=None if case["zero"] is None else ZeroPointDomain[case["zero"]],
+        group_shapes=case["groups"],
+        scale_dtypes=tuple(sd(x) for x in case["sdt"]),
+    )
+    if "inter" in case:
+        cfg = ProgressiveQuantizerConfig(
+            **kw,
+            intermediate_dtypes=tuple(QuantDataType.from_str(x) for x in case["inter"]),
+            intermediate_levels=case["levels"],
+        )
+    else:
+        cfg = QuantizerConfig(**kw)
+    return Quantizer(cfg, default_dtype=default_dtype)
+
+
+def _np(t: torch.Tensor) -> np.ndarray:
+    return t.detach().to(torch.float32).cpu().numpy()
+
+
+def gen_fake_quant(ref) -> None:
+    from deepcompressor.data.range import DynamicRange
+
+    meta = {}
+    arrays = {}
+    jobs = [(name, name, None) for name in FAKE_QUANT_CASES] + [(k, v[0], v[1]) for k, v in DYN_CASES.items()]
+    for key, cname, dyn in jobs:
+        case = FAKE_QUANT_CASES[cname]
+        for dt in ("bf16", "f16", "f32"):
+            if dyn is not None and dt != "bf16":
+                continue
+            w = _mk_input(case["shape"], dt, seed=hash((cname, dt)) % 1000 if False else len(cname) * 7 + len(dt))
+            q = _build_quantizer(ref, case)
+            kwargs = {}
+            if dyn is not None:
+                kwargs["dynamic_range"] = DynamicRange(ratio=dyn["ratio"])
+            codes = q.quantize(w, return_with_dequant=False, return_with_quant=True, **kwargs)
+            deq = q.quantize(w, return_with_dequant=True, return_with_quant=False, **kwargs)
+            tag = f"{key}|{dt}"
+            arrays[f"{tag}|x"] = _np(w)
+            arrays[f"{tag}|codes"] = _np(codes.qdata)
+            arrays[f"{tag}|dequant"] = _np(deq.data)
+            arrays[f"{tag}|scale"] = _np(codes.scale.data)
+            sd = codes.scale.state_dict("s")
+            for lvl, leaf in enumerate(sd.values()):
+                arrays[f"{tag}|leaf{lvl}"] = _np(leaf)
+            arrays[f"{tag}|zero"] = _np(codes.zero)
+            meta[tag] = dict(case=cname, in_dtype=dt, dyn=dyn, view_shape=list(codes.view_shape), n_leaves=len(sd),
+                             codebook_via_restatement=case["dtype"].startswith("sfp")
+                             or any(isinstance(s, str) and s.startswith("sfp") for s in case["sdt"]))
+    np.savez_compressed(os.path.join(OUT, "fake_quant.npz"), **arrays)
+    with open(os.path.join(OUT, "fake_quant.json"), "w") as f:
+        json.dump(dict(cases={k: {kk: vv for kk, vv in v.items() if kk != "shape"} | {"shape": list(v["shape"])}
+                              for k, v in FAKE_QUANT_CASES.items()}, entries=meta), f, indent=1)
+
+
+def gen_range_search(ref) -> None:
+    import torch.nn as nn
+    from deepcompressor.calib.config import (
+        DynamicRangeCalibConfig,
+        SearchBasedCalibGranularity,
+        SearchBasedCalibObjective,
+        SearchBasedCalibStrategy,
+    )
+    from deepcompressor.calib.range import DynamicRangeCalibrator
+    from deepcompressor.data.cache import TensorCache, TensorsCache
+    from deepcompressor.data.common import TensorType
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+
+    arrays, meta = {}, {}
+    plan = [
+        ("sint4_g128_f16s", "bf16", 2.4, 100), ("sint4_g128_f16s", "f16", 2.4, 100),
+        ("sint4_g128_f16s", "f32", 2.4, 100), ("sint4_g128_f16s", "bf16", 2, 80),
+        ("uint4_post_g128_f16s", "bf16", 2.4, 100), ("uint4_post_g128_f16s", "f16", 2.4, 100),
+        ("uint4_pre_g128_f16s", "bf16", 2.4, 100), ("sint4_g64_defs", "bf16", 2.4, 100),
+        ("sint4_g64_defs", "f16", 2, 80), ("sint4_gchn_f16s", "bf16", 2.4, 100), ("sint8_gchn_f16s", "f16", 2, 80),
+        ("sfp4_g32_f16s", "bf16", 2.4, 100), ("uint4_post_g128_f16s", "bf16", 3, 40),
+    ]
+    for cname, dt, degree, grids in plan:
+        case = FAKE_QUANT_CASES[cname]
+        w = _mk_input(case["shape"], dt, seed=1000 + len(cname) + len(dt))
+        q = _build_quantizer(ref, case)
+        cfg = DynamicRangeCalibConfig(
+            degree=degree, objective=SearchBasedCalibObjective.TensorError, strategy=SearchBasedCalibStrategy.GridSearch,
+            granularity=SearchBasedCalibGranularity.Group, max_shrink=0.2, max_expand=1.0, num_grids=grids,
+        )
+        cal = DynamicRangeCalibrator(TensorType.Weights, cfg, static=True, quantizer=q)
+        errors = []
+        orig_tell = cal._tell
+
+        def tell(error, _orig=orig_tell, _errors=errors):
+            _errors.append(_np(error[0]).copy())
+            _orig(error)
+
+        cal._tell = tell
+        dummy = TensorsCache(TensorCache([torch.zeros(1, 8, w.shape[-1])], channels_dim=-1, reshape=LinearReshapeFn()))
+        best = cal.calibrate(x_wgts=[nn.Parameter(w, requires_grad=False)], eval_inputs=dummy)
+        tag = f"{cname}|{dt}|d{degree}|g{grids}"
+        arrays[f"{tag}|x"] = _np(w)
+        arrays[f"{tag}|max"] = _np(best.max)
+        if best.min is not None:
+            arrays[f"{tag}|min"] = _np(best.min)
+        arrays[f"{tag}|ratio"] = _np(cal.best_range.ratio)
+        arrays[f"{tag}|best_error"] = _np(cal.best_error)
+        arrays[f"{tag}|errors"] = np.stack(errors)
+        arrays[f"{tag}|ratios"] = np.asarray([r for it in cal.ratios for r in it], dtype=np.float64)
+        meta[tag] = dict(case=cname, in_dtype=dt, degree=degree, num_grids=grids,
+                         codebook_via_restatement=case["dtype"].startswith("sfp"))
+    np.savez_compressed(os.path.join(OUT, "range_search.npz"), **arrays)
+    with open(os.path.join(OUT, "range_search.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+def gen_tables(ref) -> None:
+    """pow tables over every finite non-negative 16-bit input, ATen sum-order samples, codebooks, protective ranges."""
+    from deepcompressor.data.dtype import QuantDataType
+    from deepcompressor.data.range import ProtectiveQuantRange
+    from deepcompressor.data.zero import ZeroPointDomain
+
+    arrays = {}
+    for dt, end in (("bf16", 0x7F80), ("f16", 0x7C00)):
+        bits = torch.arange(0, end, dtype=torch.int32).to(torch.int16)
+        a = bits.view(TORCH_DT[dt])
+        for degree in (2.4, 2, 3, 1.5, 2.5, 4, 1, 2.2):
+            p = a.clone().pow_(degree)
+            arrays[f"pow|{dt}|{degree}"] = p.view(torch.int16).numpy().astype(np.uint16)
+    g = torch.Generator().manual_seed(7)
+    for dt in ("bf16", "f16", "f32"):
+        for S in (8, 16, 32, 64, 96, 128, 200, 256, 512, 4096):
+            x = (torch.rand(192 if S <= 512 else 24, S, generator=g) ** 3 * 1e-3).to(TORCH_DT[dt])
+            arrays[f"sum|{dt}|{S}|x"] = _np(x)
+            arrays[f"sum|{dt}|{S}|y"] = _np(x.sum(dim=-1))
+    for name in ("sfp4_e2m1_all", "sfp8_e4m3_nan", "sfp8_e5m2_inf", "ufp4_e2m2_all", "sfp6_e3m2_all", "sfp6_e2m3_all",
+                 "sint4", "uint4", "smag4"):
+        arrays[f"codebook|{name}"] = QuantDataType.from_str(name).get_codebook().values.numpy().astype(np.float32)
+    prot = {}
+    for outer, inner, zd in (("sint8", "uint4", "PostScale"), ("sint8", "uint4", "PreScale"),
+                             ("sint8", "sint4", "PostScale"), ("sint8", "sint4", "PreScale"), ("sint8", "sint4", None)):
+        r = ProtectiveQuantRange.construct(QuantDataType.from_str(outer), QuantDataType.from_str(inner),
+                                           None if zd is None else ZeroPointDomain[zd])
+        prot[f"{outer}|{inner}|{zd}"] = [r.min, r.max]
+    # dtype scalar properties
+    props = {}
+    for name in ("sint4", "uint4", "sint8", "uint8", "smag4", "sfp4_e2m1_all", "sfp8_e4m3_nan", "sfp8_e5m2_inf",
+                 "sfp6_e3m2_all", "uexp8_all", "sexp4_nan", "ufp4_e2m2_all"):
+        d = QuantDataType.from_str(name)
+        props[name] = dict(min=d.min_value, max=d.max_value, max_exp=d.max_exponent_value, min_exp=d.min_exponent_value,
+                           is_exp=d.is_exponent, is_fp=d.is_float_point, signed=d.signed, bits=d.total_bits)
+    np.savez_compressed(os.path.join(OUT, "tables.npz"), **arrays)
+    with open(os.path.join(OUT, "tables.json"), "w") as f:
+        json.dump(dict(protective=prot, dtype_props=props), f, indent=1)
+
+
+def gen_gptq(ref) -> None:
+    from deepcompressor.data.cache import TensorCache
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+    from deepcompressor.quantizer.kernel.gptq import QuantGptqConfig
+
+    arrays, meta = {}, {}
+    for cname, dt, R, C, T in (("uint4_post_g128_f16s", "bf16", 96, 512, 1024), ("sint4_g128_f16s", "f16", 64, 256, 512),
+                               ("sint4_g64_defs", "bf16", 64, 256, 512)):
+        g = torch.Generator().manual_seed(R + C)
+        w = (torch.randn(R, C, generator=g) * 0.02).to(TORCH_DT[dt])
+        gains = torch.exp(torch.randn(C, generator=g))
+        x = (torch.randn(2, T // 2, C, generator=g) * gains).to(TORCH_DT[dt])
+        x[..., 5] = 0  # a dead input channel
+        case = FAKE_QUANT_CASES[cname]
+        q = _build_quantizer(ref, case)
+        cache = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_cached=1, num_total=1, num_samples=T)
+        kern = QuantGptqConfig(damp_percentage=0.01, block_size=128, num_inv_tries=250, hessian_block_size=512)
+        qt = q.quantize(w, kernel=kern, inputs=cache, return_with_dequant=False, return_with_quant=True)
+        dq = q.quantize(w, kernel=kern, inputs=cache, return_with_dequant=True, return_with_quant=False)
+        rtn = q.quantize(w, return_with_dequant=True, return_with_quant=False)
+        tag = f"{cname}|{dt}|{R}x{C}|T{T}"
+        arrays[f"{tag}|w"] = _np(w)
+        arrays[f"{tag}|x"] = _np(x)
+        arrays[f"{tag}|codes"] = _np(qt.qdata)
+        arrays[f"{tag}|dequant"] = _np(dq.data)
+        arrays[f"{tag}|rtn_dequant"] = _np(rtn.data)
+        arrays[f"{tag}|scale"] = _np(qt.scale.data)
+        arrays[f"{tag}|zero"] = _np(qt.zero)
+        meta[tag] = dict(case=cname, in_dtype=dt, R=R, C=C, T=T, damp=0.01, block=128, num_samples=T)
+    np.savez_compressed(os.path.join(OUT, "gptq.npz"), **arrays)
+    with open(os.path.join(OUT, "gptq.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+def main() -> None:
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = load_reference()
+    which = sys.argv[1:] or ["fake_quant", "range_search", "tables", "gptq"]
+    for name in which:
+        globals()[f"gen_{name}"](ref)
+        print("generated", name)
+
+
+if __name__ == "__main__":
+    main()
