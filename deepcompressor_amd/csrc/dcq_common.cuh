@@ -1,0 +1,191 @@
+// Device-side helpers shared by the quantization kernels (gfx950 only).
+//
+// Numerical contract: everything here is plain IEEE float32 with round-to-nearest-even and must be
+// compiled with -ffp-contract=off (a fused multiply-add would change results that the reference
+// computes as two rounded operations).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "dcq.h"
+
+namespace dcq {
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------------------------
+// host-side error reporting
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_check(hipError_t e, const char* what);
+
+#define DCQ_REQUIRE(cond, code, ...) \
+  do {                               \
+    if (!(cond)) {                   \
+      ::dcq::set_error(__VA_ARGS__); \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+#define DCQ_LAUNCH_CHECK(name)                                       \
+  do {                                                               \
+    int _rc = ::dcq::hip_check(hipGetLastError(), name);             \
+    if (_rc != DCQ_OK) return _rc;                                   \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// storage types
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(static_cast<uint32_t>(b) << 16); }
+
+__device__ __forceinline__ uint16_t f32_to_bf16(float x) {
+  uint32_t u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);  // keep NaN a NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+
+__device__ __forceinline__ float f16_to_f32(uint16_t b) { return __half2float(__ushort_as_half(b)); }
+__device__ __forceinline__ uint16_t f32_to_f16(float x) { return __half_as_ushort(__float2half_rn(x)); }
+
+template <int ST>
+struct Storage;
+
+template <>
+struct Storage<DCQ_F32> {
+  using elem_t = float;
+  static constexpr int kVec = 4;  // elements per 16-byte access
+  static __device__ __forceinline__ float load(elem_t v) { return v; }
+  static __device__ __forceinline__ elem_t store(float v) { return v; }
+  static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <>
+struct Storage<DCQ_F16> {
+  using elem_t = uint16_t;
+  static constexpr int kVec = 8;
+  static __device__ __forceinline__ float load(elem_t v) { return f16_to_f32(v); }
+  static __device__ __forceinline__ elem_t store(float v) { return f32_to_f16(v); }
+  static __device__ __forceinline__ float round(float v) { return f16_to_f32(f32_to_f16(v)); }
+};
+template <>
+struct Storage<DCQ_BF16> {
+  using elem_t = uint16_t;
+  static constexpr int kVec = 8;
+  static __device__ __forceinline__ float load(elem_t v) { return bf16_to_f32(v); }
+  static __device__ __forceinline__ elem_t store(float v) { return f32_to_bf16(v); }
+  static __device__ __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+};
+
+// A 16-byte (or, for VEC == 1, single element) chunk of a tensor.
+template <typename E, int VEC>
+struct alignas(sizeof(E) * VEC) Chunk {
+  E v[VEC];
+};
+
+template <typename E, int VEC>
+__device__ __forceinline__ Chunk<E, VEC> load_chunk(const E* p) {
+  return *reinterpret_cast<const Chunk<E, VEC>*>(p);
+}
+template <typename E, int VEC>
+__device__ __forceinline__ void store_chunk(E* p, const Chunk<E, VEC>& c) {
+  *reinterpret_cast<Chunk<E, VEC>*>(p) = c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// codebook search: largest index lo with cb[lo] <= x (0 if none); tie between the two neighbours goes up
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float codebook_nearest(float x, const float* cb, int C) {
+  int lo = 0;
+  float lval = cb[0];
+#pragma unroll 1
+  for (int bit = 1 << (31 - __clz(C)); bit; bit >>= 1) {
+    const int next = lo | bit;
+    const float nval = cb[next < C ? next : C - 1];
+    const bool take = next < C && nval <= x;
+    lo = take ? next : lo;
+    lval = take ? nval : lval;
+  }
+  const float hval = cb[lo + (lo < C - 1)];
+  return (x + x < lval + hval) ? lval : hval;
+}
+
+// One application of a dcq_rounding.  `cb` points at the (LDS or global) copy of r.codebook.
+__device__ __forceinline__ float apply_rounding(const dcq_rounding& r, float v, const float* cb) {
+  float y;
+  switch (r.kind) {
+    case DCQ_ROUND_F16:
+      y = f16_to_f32(f32_to_f16(v));
+      break;
+    case DCQ_ROUND_BF16:
+      y = bf16_to_f32(f32_to_bf16(v));
+      break;
+    case DCQ_ROUND_INT:
+      return fminf(fmaxf(rintf(v), r.lo), r.hi);
+    case DCQ_ROUND_CODEBOOK:
+      y = codebook_nearest(fminf(fmaxf(v, r.lo), r.hi), cb, r.codebook_size);
+      break;
+    case DCQ_ROUND_EXP:
+      return exp2f(fminf(fmaxf(floorf(log2f(v)), r.lo), r.hi));
+    default:
+      y = v;
+      break;
+  }
+  if (r.has_clamp) y = fminf(fmaxf(y, r.clamp_lo), r.clamp_hi);
+  return y;
+}
+
+// Integer fast path of apply_rounding (kind known at compile time).
+__device__ __forceinline__ float round_int(float v, float lo, float hi) { return fminf(fmaxf(rintf(v), lo), hi); }
+
+// ---------------------------------------------------------------------------------------------
+// per-group scale / zero from a (already ratio-scaled) range, single scale level
+// ---------------------------------------------------------------------------------------------
+struct ScaleZero {
+  float s, z;
+};
+
+__device__ __forceinline__ ScaleZero scale_zero_from_range(const dcq_step& st, float vmax, float vmin,
+                                                           const float* s_cb, const float* z_cb) {
+  if (st.has_bound_max) vmax = fminf(vmax, st.bound_max);
+  if (st.zero_domain != DCQ_ZERO_NONE && st.has_bound_min) vmin = fmaxf(vmin, st.bound_min);
+  const float span = st.zero_domain != DCQ_ZERO_NONE ? vmax - vmin : vmax;
+  float s = apply_rounding(st.scale, fabsf(span / st.q_span), s_cb);
+  if (s == 0.0f) s = 1.0f;
+  float z = 0.0f;
+  if (st.zero_domain == DCQ_ZERO_PRE_SCALE) {
+    z = apply_rounding(st.zero, st.q_min - vmin / s, z_cb);
+  } else if (st.zero_domain == DCQ_ZERO_POST_SCALE) {
+    z = apply_rounding(st.zero, st.q_min * s - vmin, z_cb);
+  }
+  return {s, z};
+}
+
+template <int ZD>
+__device__ __forceinline__ float to_code_input(float x, float s, float z) {
+  float t = x;
+  if (ZD == DCQ_ZERO_POST_SCALE) t = t + z;
+  t = t / s;
+  if (ZD == DCQ_ZERO_PRE_SCALE) t = t + z;
+  return t;
+}
+
+template <int ZD>
+__device__ __forceinline__ float from_code(float q, float s, float z) {
+  if (ZD == DCQ_ZERO_PRE_SCALE) return (q - z) * s;
+  if (ZD == DCQ_ZERO_POST_SCALE) return q * s - z;
+  return q * s;
+}
+
+// xor-butterfly reductions over `width` adjacent lanes (width a power of two <= 64)
+__device__ __forceinline__ float team_max(float v, int width) {
+  for (int off = width >> 1; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+__device__ __forceinline__ float team_min(float v, int width) {
+  for (int off = width >> 1; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+
+}  // namespace dcq

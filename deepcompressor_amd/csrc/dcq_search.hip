@@ -1,0 +1,385 @@
+// Fused range-ratio grid search (gfx950): every candidate ratio of every group in one pass over
+// the weights.
+//
+// The reference evaluates one candidate at a time over the whole tensor and sums each group's error
+// with the torch CPU backend, whose reduction is an 8-lane float32 SIMD loop.  To reproduce its
+// result bit for bit the kernel mirrors that loop: a team of 8 GPU lanes owns one group and lane j
+// holds exactly the elements SIMD lane j accumulates (element index = j mod 8), so the vector part
+// of the sum happens in registers in the reference's order and only the final 8-way fold crosses
+// lanes (DPP row shifts).  A wave therefore works on 8 groups; the weights are read from HBM once,
+// transposed through a small per-wave LDS tile, and all K candidates are evaluated from registers.
+//
+// |Q(w) - w|^degree is evaluated in the weight's storage type.  For 16-bit storage the value is a
+// pure function of the 15-bit magnitude pattern, so the block keeps the whole function as a 64 KiB
+// table in LDS (built once per (dtype, degree) by dcq_pow_table) and the power costs one LDS read.
+#include <string.h>
+
+#include "dcq_common.cuh"
+
+namespace dcq {
+
+constexpr int kTeam = 8;                       // lanes per group = SIMD width of the mirrored reduction
+constexpr int kGroupsPerWave = kWave / kTeam;  // 8
+constexpr int kTableEntries = 32768;
+
+// Threads per block by values per lane: 16 waves share one 64 KiB table per CU while the registers
+// allow it (<= 128 VGPRs at 16 elements per lane); longer groups trade waves for registers and LDS.
+constexpr int search_block(int npl) { return npl <= 16 ? 1024 : (npl == 32 ? 512 : 256); }
+
+enum PowMode { kPowTable = 0, kPowSquare = 1, kPowFloat = 2 };
+
+struct SearchParams {
+  dcq_step step;
+  const void* w;
+  int64_t G;
+  int32_t S;
+  const float* ratios;
+  int32_t K;
+  float degree;
+  const uint16_t* table;
+  float* best_max;
+  float* best_min;
+  float* best_ratio;
+  float* best_error;
+  float* errors;
+};
+
+// hardware float32 -> bfloat16 (round-to-nearest-even) used in the hot loop
+__device__ __forceinline__ uint16_t f32_to_bf16_fast(float x) {
+  const __bf16 h = static_cast<__bf16>(x);
+  return __builtin_bit_cast(uint16_t, h);
+}
+
+template <int ST>
+__device__ __forceinline__ uint16_t to_bits16(float v) {
+  return ST == DCQ_BF16 ? f32_to_bf16_fast(v) : f32_to_f16(v);
+}
+template <int ST>
+__device__ __forceinline__ float from_bits16(uint16_t b) {
+  return ST == DCQ_BF16 ? bf16_to_f32(b) : f16_to_f32(b);
+}
+
+// lane i of each 16-lane row receives lane i-1's value (row_shr:1)
+__device__ __forceinline__ float row_shift_right1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
+}
+
+template <int ST, int NPL, int ZD, int POW, bool INT_Q>
+__global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const SearchParams p) {
+  constexpr int kSearchBlock = search_block(NPL);
+  constexpr int kGroupsPerBlock = kSearchBlock / kTeam;
+  using St = Storage<ST>;
+  using elem_t = typename St::elem_t;
+  constexpr int EB = sizeof(elem_t);
+  constexpr int S = NPL * kTeam;
+  constexpr int kRowBytes = S * EB + 16;  // +16: consecutive groups start 4 banks apart
+  constexpr int kPiecesPerGroup = S * EB / 16;
+  constexpr bool PAIR = ST != DCQ_F32;  // a 16-element load is folded to 8 float lanes by one add
+  constexpr int NV = PAIR ? NPL / 2 : NPL;
+  constexpr int ROWS = NV / 4;
+  static_assert(!PAIR || NPL % 2 == 0, "16-bit groups must be a multiple of 16 elements");
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint16_t* table = reinterpret_cast<uint16_t*>(smem);
+  constexpr int kTableBytes = POW == kPowTable ? kTableEntries * 2 : 0;
+  float* cbs = reinterpret_cast<float*>(smem + kTableBytes);  // [3][256] codebooks
+  unsigned char* stage = smem + kTableBytes + 3 * 256 * 4;
+
+  const dcq_step& st = p.step;
+  if (POW == kPowTable) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.table);
+    uint4* dst = reinterpret_cast<uint4*>(table);
+    for (int i = threadIdx.x; i < kTableEntries * 2 / 16; i += kSearchBlock) dst[i] = src[i];
+  }
+  {
+    const dcq_rounding* r[3] = {&st.tensor, &st.scale, &st.zero};
+    for (int k = 0; k < 3; ++k)
+      if (r[k]->kind == DCQ_ROUND_CODEBOOK)
+        for (int i = threadIdx.x; i < r[k]->codebook_size; i += kSearchBlock) cbs[k * 256 + i] = r[k]->codebook[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int j = lane & (kTeam - 1);  // mirrored SIMD lane
+  const int gw = lane / kTeam;       // group within the wave
+  unsigned char* wstage = stage + wave * (kGroupsPerWave * kRowBytes);
+  const elem_t* w = static_cast<const elem_t*>(p.w);
+
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kGroupsPerBlock; base < p.G;
+       base += static_cast<int64_t>(gridDim.x) * kGroupsPerBlock) {
+    const int64_t wbase = base + wave * kGroupsPerWave;  // first group of this wave
+    const int64_t g = wbase + gw;
+    // ---- HBM -> LDS, 16 bytes per lane, coalesced over the wave's 8 consecutive groups
+    for (int piece = lane; piece < kGroupsPerWave * kPiecesPerGroup; piece += kWave) {
+      const int gi = piece / kPiecesPerGroup, within = piece % kPiecesPerGroup;
+      if (wbase + gi < p.G) {
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(w + (wbase + gi) * S) +
+                                                        within * 16);
+        *reinterpret_cast<uint4*>(wstage + gi * kRowBytes + within * 16) = v;
+      }
+    }
+    // ---- LDS -> registers, lane j takes elements j, j+8, j+16, ... (same wave wrote them: no barrier needed)
+    float x[NPL];
+    const bool live = g < p.G;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const elem_t raw = *reinterpret_cast<const elem_t*>(wstage + gw * kRowBytes + (i * kTeam + j) * EB);
+      x[i] = live ? St::load(raw) : 0.0f;
+    }
+    // ---- base range (DynamicRange.construct)
+    float bmax, bmin = 0.0f;
+    {
+      float mx = ZD == DCQ_ZERO_NONE ? 0.0f : -INFINITY, mn = INFINITY;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        if (ZD == DCQ_ZERO_NONE) {
+          mx = fmaxf(mx, fabsf(x[i]));
+        } else {
+          mx = fmaxf(mx, x[i]);
+          mn = fminf(mn, x[i]);
+        }
+      }
+      bmax = team_max(mx, kTeam);
+      if (ZD != DCQ_ZERO_NONE) bmin = team_min(mn, kTeam);
+      if (ZD == DCQ_ZERO_PRE_SCALE) {
+        bmax = fmaxf(bmax, 0.0f);
+        bmin = fminf(bmin, 0.0f);
+      }
+    }
+    float best_err = 0.0f;
+    int best_k = 0;
+    for (int k = 0; k < p.K; ++k) {
+      const float r = p.ratios[k];
+      float cmax = bmax * r, cmin = 0.0f;
+      if (ZD != DCQ_ZERO_NONE) cmin = bmin * r;
+      if (ZD == DCQ_ZERO_PRE_SCALE) {
+        cmax = fmaxf(cmax, 0.0f);
+        cmin = fminf(cmin, 0.0f);
+      }
+      const ScaleZero sz = scale_zero_from_range(st, cmax, cmin, cbs + 256, cbs + 512);
+      float pw[NPL];
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const float t = to_code_input<ZD>(x[i], sz.s, sz.z);
+        const float q = INT_Q ? round_int(t, st.tensor.lo, st.tensor.hi) : apply_rounding(st.tensor, t, cbs);
+        const float d = from_code<ZD>(q, sz.s, sz.z);
+        if (ST == DCQ_F32) {
+          const float a = fabsf(d - x[i]);
+          pw[i] = POW == kPowSquare ? a * a : powf(a, p.degree);
+        } else {
+          const float dq = from_bits16<ST>(to_bits16<ST>(d));             // Q(w) in the weight dtype
+          const uint16_t eb = to_bits16<ST>(dq - x[i]) & 0x7fffu;         // |Q(w) - w| in the weight dtype
+          if (POW == kPowTable) {
+            pw[i] = from_bits16<ST>(table[eb]);
+          } else {
+            const float a = from_bits16<ST>(eb);
+            pw[i] = from_bits16<ST>(to_bits16<ST>(a * a));
+          }
+        }
+      }
+      // ---- the reference's vectorised inner sum, lane-local part
+      float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int m = 0; m < NV; ++m) {
+        const float v = PAIR ? pw[2 * m] + pw[2 * m + 1] : pw[m];
+        const int slot = m < ROWS * 4 ? (m & 3) : 0;
+        acc[slot] = acc[slot] + v;
+      }
+      const float part = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+      // ---- left-to-right fold over the 8 lanes: y_j = y_{j-1} + part_j
+      float y = part;
+#pragma unroll
+      for (int t = 1; t < kTeam; ++t) {
+        const float prev = row_shift_right1(y);
+        y = j == 0 ? part : prev + part;
+      }
+      const float err = St::round(y);  // valid in lane j == 7
+      if (p.errors && j == kTeam - 1 && live) p.errors[static_cast<int64_t>(k) * p.G + g] = err;
+      if (k == 0 || err < best_err) {
+        best_err = err;
+        best_k = k;
+      }
+    }
+    if (j == kTeam - 1 && live) {
+      const float r = p.ratios[best_k];
+      float cmax = bmax * r, cmin = 0.0f;
+      if (ZD != DCQ_ZERO_NONE) cmin = bmin * r;
+      if (ZD == DCQ_ZERO_PRE_SCALE) {
+        cmax = fmaxf(cmax, 0.0f);
+        cmin = fminf(cmin, 0.0f);
+      }
+      p.best_max[g] = cmax;
+      if (ZD != DCQ_ZERO_NONE && p.best_min) p.best_min[g] = cmin;
+      if (p.best_ratio) p.best_ratio[g] = r;
+      if (p.best_error) p.best_error[g] = best_err;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pow table
+// ---------------------------------------------------------------------------------------------
+template <int ST>
+__global__ __launch_bounds__(256) void pow_table_kernel(uint16_t* table, double degree, int special) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kTableEntries) return;
+  const float a = Storage<ST>::load(static_cast<uint16_t>(i));
+  float r;
+  if (special == 2) {
+    r = a * a;
+  } else if (special == 3) {
+    r = Storage<ST>::round(a * a) * a;
+  } else {
+    r = static_cast<float>(pow(static_cast<double>(a), degree));
+  }
+  table[i] = Storage<ST>::store(r);
+}
+
+static double round_degree_to_storage(double degree, int storage) {
+  // float -> storage -> double, on the host (bit manipulation; no fp16 hardware assumed)
+  const float f = static_cast<float>(degree);
+  uint32_t u;
+  ::memcpy(&u, &f, 4);
+  if (storage == DCQ_BF16) {
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    float o;
+    ::memcpy(&o, &u, 4);
+    return o;
+  }
+  // float16: normal range only (degrees are small positive numbers)
+  const int exp = static_cast<int>((u >> 23) & 0xff) - 127;
+  if (exp < -14 || exp > 15) return f;
+  const uint32_t keep = 13;  // 23 - 10 mantissa bits dropped
+  u += (1u << (keep - 1)) - 1 + ((u >> keep) & 1u);
+  u &= ~((1u << keep) - 1);
+  float o;
+  ::memcpy(&o, &u, 4);
+  return o;
+}
+
+template <int ST, int NPL, int ZD, int POW>
+static int launch_search(const SearchParams& p, hipStream_t stream) {
+  constexpr int EB = sizeof(typename Storage<ST>::elem_t);
+  constexpr int kSearchBlock = search_block(NPL);
+  constexpr int kGroupsPerBlock = kSearchBlock / kTeam;
+  const size_t lds = (POW == kPowTable ? kTableEntries * 2 : 0) + 3 * 256 * 4 +
+                     static_cast<size_t>(kSearchBlock / kWave) * kGroupsPerWave * (NPL * kTeam * EB + 16);
+  int64_t blocks = (p.G + kGroupsPerBlock - 1) / kGroupsPerBlock;
+  if (blocks > 256) blocks = 256;
+  const bool int_q = p.step.tensor.kind == DCQ_ROUND_INT;
+  auto kern = int_q ? range_search_kernel<ST, NPL, ZD, POW, true> : range_search_kernel<ST, NPL, ZD, POW, false>;
+  if (lds > 64 * 1024) {
+    int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),
+                       "hipFuncSetAttribute(max dynamic LDS)");
+    if (rc != DCQ_OK) return rc;
+  }
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kSearchBlock), lds, stream, p);
+  DCQ_LAUNCH_CHECK("range_search_kernel launch");
+  return DCQ_OK;
+}
+
+template <int ST, int NPL, int POW>
+static int search_zero(const SearchParams& p, hipStream_t stream) {
+  switch (p.step.zero_domain) {
+    case DCQ_ZERO_NONE:
+      return launch_search<ST, NPL, DCQ_ZERO_NONE, POW>(p, stream);
+    case DCQ_ZERO_PRE_SCALE:
+      return launch_search<ST, NPL, DCQ_ZERO_PRE_SCALE, POW>(p, stream);
+    default:
+      return launch_search<ST, NPL, DCQ_ZERO_POST_SCALE, POW>(p, stream);
+  }
+}
+
+template <int ST, int POW>
+static int search_size(const SearchParams& p, hipStream_t stream) {
+  switch (p.S / kTeam) {
+    case 2:
+      return search_zero<ST, 2, POW>(p, stream);
+    case 4:
+      return search_zero<ST, 4, POW>(p, stream);
+    case 8:
+      return search_zero<ST, 8, POW>(p, stream);
+    case 16:
+      return search_zero<ST, 16, POW>(p, stream);
+    case 32:
+      return search_zero<ST, 32, POW>(p, stream);
+    case 64:
+      return search_zero<ST, 64, POW>(p, stream);
+    default:
+      set_error("range search: group size %d is not one of 16, 32, 64, 128, 256, 512", p.S);
+      return DCQ_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace dcq
+
+using namespace dcq;
+
+extern "C" {
+
+int dcq_pow_table(int32_t storage, double degree, uint16_t* table, dcq_stream_t stream) {
+  DCQ_REQUIRE(table != nullptr, DCQ_ERR_ARGUMENT, "table is NULL");
+  DCQ_REQUIRE(storage == DCQ_F16 || storage == DCQ_BF16, DCQ_ERR_ARGUMENT, "pow table exists for 16-bit storage only");
+  const double d = round_degree_to_storage(degree, storage);
+  // torch's bfloat16 pow special-cases 2 and 3 as repeated multiplication in bfloat16; float16 has no such case
+  int special = 0;
+  if (storage == DCQ_BF16 && d == 2.0) special = 2;
+  if (storage == DCQ_BF16 && d == 3.0) special = 3;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (storage == DCQ_BF16) {
+    hipLaunchKernelGGL(pow_table_kernel<DCQ_BF16>, dim3(kTableEntries / 256), dim3(256), 0, s, table, d, special);
+  } else {
+    hipLaunchKernelGGL(pow_table_kernel<DCQ_F16>, dim3(kTableEntries / 256), dim3(256), 0, s, table, d, special);
+  }
+  DCQ_LAUNCH_CHECK("pow_table_kernel launch");
+  return DCQ_OK;
+}
+
+int dcq_range_search_groups(const dcq_step* step, const void* w, int32_t storage, int64_t G, int64_t S,
+                            const float* ratios, int32_t K, double degree, const uint16_t* pow_table, float* best_max,
+                            float* best_min, float* best_ratio, float* best_error, float* errors,
+                            dcq_stream_t stream) {
+  DCQ_REQUIRE(step != nullptr, DCQ_ERR_ARGUMENT, "step is NULL");
+  DCQ_REQUIRE(step->tensor.kind == DCQ_ROUND_INT || step->tensor.kind == DCQ_ROUND_CODEBOOK, DCQ_ERR_UNSUPPORTED,
+              "tensor dtype must be an integer or a codebook type");
+  DCQ_REQUIRE(!(step->tensor.kind == DCQ_ROUND_CODEBOOK && step->zero_domain != DCQ_ZERO_NONE), DCQ_ERR_UNSUPPORTED,
+              "floating-point dtype with a zero point is not implemented");
+  DCQ_REQUIRE(G >= 0 && S > 0 && K > 0, DCQ_ERR_ARGUMENT, "bad sizes G=%lld S=%lld K=%d", (long long)G, (long long)S, K);
+  if (G == 0) return DCQ_OK;
+  DCQ_REQUIRE(w && ratios && best_max, DCQ_ERR_ARGUMENT, "NULL buffer");
+  DCQ_REQUIRE((reinterpret_cast<uintptr_t>(w) & 15u) == 0, DCQ_ERR_ARGUMENT, "w must be 16-byte aligned");
+  DCQ_REQUIRE(step->zero_domain == DCQ_ZERO_NONE || best_min, DCQ_ERR_ARGUMENT, "best_min is NULL");
+  DCQ_REQUIRE(S <= 512 && S % (storage == DCQ_F32 ? 8 : 16) == 0, DCQ_ERR_UNSUPPORTED,
+              "range search: group size %lld unsupported (multiple of 16, at most 512)", (long long)S);
+  SearchParams p{};
+  p.step = *step;
+  p.w = w;
+  p.G = G;
+  p.S = static_cast<int32_t>(S);
+  p.ratios = ratios;
+  p.K = K;
+  p.table = pow_table;
+  p.best_max = best_max;
+  p.best_min = best_min;
+  p.best_ratio = best_ratio;
+  p.best_error = best_error;
+  p.errors = errors;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (storage == DCQ_F32) {
+    p.degree = static_cast<float>(degree);
+    return p.degree == 2.0f ? search_size<DCQ_F32, kPowSquare>(p, s) : search_size<DCQ_F32, kPowFloat>(p, s);
+  }
+  DCQ_REQUIRE(storage == DCQ_F16 || storage == DCQ_BF16, DCQ_ERR_ARGUMENT, "bad storage %d", storage);
+  const double d = round_degree_to_storage(degree, storage);
+  if (d == 2.0) {
+    return storage == DCQ_BF16 ? search_size<DCQ_BF16, kPowSquare>(p, s) : search_size<DCQ_F16, kPowSquare>(p, s);
+  }
+  DCQ_REQUIRE(pow_table != nullptr, DCQ_ERR_ARGUMENT, "pow_table is NULL (build it with dcq_pow_table)");
+  DCQ_REQUIRE((reinterpret_cast<uintptr_t>(pow_table) & 15u) == 0, DCQ_ERR_ARGUMENT, "pow_table must be 16-byte aligned");
+  return storage == DCQ_BF16 ? search_size<DCQ_BF16, kPowTable>(p, s) : search_size<DCQ_F16, kPowTable>(p, s);
+}
+
+}  // extern "C"

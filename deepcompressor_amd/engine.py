@@ -1,0 +1,270 @@
+"""Thin host layer over the C ABI: canonical group layout, descriptor building, kernel calls.
+
+Nothing in here computes on tensors with torch; torch allocates outputs, permutes layouts that the
+kernels cannot address directly, and provides the stream.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Rounding, Step, check, lib, ptr, storage_of, stream_of
+from .data.dtype import QuantDataType
+from .data.range import LogQuantRange, QuantRange
+from .data.zero import ZeroPointDomain
+
+__all__ = ["canonical_groups", "group_range", "make_rounding", "make_step", "fake_quant_fused", "range_to_scale",
+           "scale_level", "scale_join", "zero_point", "quantize_groups", "dequantize_groups", "simple_round",
+           "pow_table", "range_search_groups"]
+
+_ZD = {None: _lib.ZERO_NONE, ZeroPointDomain.PreScale: _lib.ZERO_PRE, ZeroPointDomain.PostScale: _lib.ZERO_POST}
+_TORCH_ROUND = {torch.float32: _lib.ROUND_F32, torch.float16: _lib.ROUND_F16, torch.bfloat16: _lib.ROUND_BF16}
+
+
+def _require_gpu(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise _lib.DcqError(f"deepcompressor_amd runs on MI355X GPUs only; got a tensor on '{t.device}' "
+                            "(there is no CPU path)")
+
+
+# ---------------------------------------------------------------------------------------------
+# layout
+# ---------------------------------------------------------------------------------------------
+def groups_are_contiguous(view_shape) -> bool:
+    """True when every group of a (#g0, gs0, #g1, gs1, ...) view is one contiguous run of a contiguous tensor."""
+    counts, sizes = view_shape[0::2], view_shape[1::2]
+    split = next((i for i, gs in enumerate(sizes) if gs > 1), len(sizes))
+    return all(c == 1 for c in counts[split + 1 :])
+
+
+def canonical_groups(tensor: torch.Tensor, view_shape):
+    """tensor -> (x[G][S] contiguous, restore) where restore maps an [G][S]-shaped result back to tensor.shape."""
+    view_shape = tuple(view_shape)
+    counts, sizes = view_shape[0::2], view_shape[1::2]
+    G, S = 1, 1
+    for c in counts:
+        G *= c
+    for s in sizes:
+        S *= s
+    shape = tensor.shape
+    if groups_are_contiguous(view_shape):
+        return tensor.contiguous().view(G, S), (lambda y: y.view(shape))
+    n = len(view_shape)
+    perm = list(range(0, n, 2)) + list(range(1, n, 2))
+    inverse = [perm.index(i) for i in range(n)]
+    x = tensor.contiguous().view(view_shape).permute(perm).reshape(G, S)
+    return x, (lambda y: y.view(*counts, *sizes).permute(inverse).reshape(shape))
+
+
+# ---------------------------------------------------------------------------------------------
+# descriptors
+# ---------------------------------------------------------------------------------------------
+_codebooks: dict[tuple[str, torch.device], torch.Tensor] = {}
+
+
+def _device_codebook(dtype: QuantDataType, device: torch.device) -> torch.Tensor:
+    key = (dtype.name, device)
+    if key not in _codebooks:
+        _codebooks[key] = dtype.get_codebook().values.to(device=device, dtype=torch.float32).contiguous()
+    return _codebooks[key]
+
+
+def make_rounding(dtype, *, has_zero_point: bool, quant_range: QuantRange | None, device: torch.device) -> Rounding:
+    """Descriptor of one ``simple_quantize(…, quant_dtype=dtype)`` call."""
+    r = Rounding()
+    extra = quant_range is not None and quant_range.is_set()
+    if isinstance(dtype, torch.dtype):
+        if dtype not in _TORCH_ROUND:
+            raise NotImplementedError(f"scale dtype {dtype} is not supported (float32, float16, bfloat16 are)")
+        r.kind = _TORCH_ROUND[dtype]
+    elif dtype.is_exponent:
+        log_range = LogQuantRange.construct(dtype, quant_range)
+        r.kind, r.lo, r.hi = _lib.ROUND_EXP, log_range.min, log_range.max
+        extra = False
+    elif dtype.is_float_point:
+        table = _device_codebook(dtype, device)
+        r.kind, r.lo, r.hi = _lib.ROUND_CODEBOOK, dtype.min_value, dtype.max_value
+        r.codebook, r.codebook_size = table.data_ptr(), table.numel()
+    else:
+        q = QuantRange.construct(dtype, has_zero_point=has_zero_point, quant_range=quant_range)
+        r.kind, r.lo, r.hi = _lib.ROUND_INT, q.min, q.max
+        extra = False
+    if extra:
+        lo = quant_range.min if quant_range.min is not None else float("-inf")
+        hi = quant_range.max if quant_range.max is not None else float("inf")
+        r.has_clamp, r.clamp_lo, r.clamp_hi = 1, lo, hi
+    return r
+
+
+def make_step(*, quant_dtype: QuantDataType, zero_domain, tensor_quant_range: QuantRange, quant_range, scale_dtype,
+              zero_dtype, range_bound, q_span: float, device: torch.device) -> Step:
+    st = Step()
+    zp = zero_domain is not None
+    st.tensor = make_rounding(quant_dtype, has_zero_point=zp, quant_range=quant_range, device=device)
+    st.scale = make_rounding(scale_dtype, has_zero_point=False, quant_range=None, device=device)
+    if zp:
+        st.zero = make_rounding(zero_dtype, has_zero_point=True, quant_range=None, device=device)
+    st.zero_domain = _ZD[zero_domain]
+    st.q_span = q_span
+    st.q_min = tensor_quant_range.min
+    if range_bound is not None:
+        if range_bound.min is not None:
+            st.has_bound_min, st.bound_min = 1, range_bound.min
+        if range_bound.max is not None:
+            st.has_bound_max, st.bound_max = 1, range_bound.max
+    return st
+
+
+def _f32(n, device) -> torch.Tensor:
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel calls
+# ---------------------------------------------------------------------------------------------
+def fake_quant_fused(step: Step, x: torch.Tensor, *, range_max=None, range_min=None, ratio=None, want_dequant=True,
+                     want_codes=False):
+    """x[G][S] -> (dequant | None, codes | None, scale[G], zero[G])."""
+    _require_gpu(x)
+    G, S = x.shape
+    dq = torch.empty_like(x) if want_dequant else None
+    codes = torch.empty((G, S), dtype=torch.float32, device=x.device) if want_codes else None
+    scale, zero = _f32(G, x.device), _f32(G, x.device)
+    check(lib().dcq_fake_quant_groups(C.byref(step), ptr(x), storage_of(x.dtype), G, S, ptr(range_max), ptr(range_min),
+                                      int(ratio is not None), float(ratio or 0.0), ptr(dq), ptr(codes), ptr(scale),
+                                      ptr(zero), stream_of(x.device)), "dcq_fake_quant_groups")
+    return dq, codes, scale, zero
+
+
+def group_range(x: torch.Tensor, *, with_min: bool, outer: torch.Tensor | None = None, outer_lo: float = 0.0,
+                outer_hi: float = 0.0):
+    _require_gpu(x)
+    G, S = x.shape
+    vmax = _f32(G, x.device)
+    vmin = _f32(G, x.device) if with_min else None
+    zd = _lib.ZERO_POST if with_min else _lib.ZERO_NONE
+    check(lib().dcq_group_range(ptr(x), storage_of(x.dtype), G, S, zd, ptr(outer), outer_lo, outer_hi, ptr(vmax),
+                                ptr(vmin), stream_of(x.device)), "dcq_group_range")
+    return vmax, vmin
+
+
+def range_to_scale(step: Step, vmax, vmin, *, ratio=None, static_max=None, static_min=None):
+    """-> (linear_scale[n], vmin'[n] | None).  vmin' is the minimum the zero point must use."""
+    ref = vmax if vmax is not None else static_max
+    n = ref.numel()
+    lin = _f32(n, ref.device)
+    zp = step.zero_domain != _lib.ZERO_NONE
+    vmin_io = None
+    if zp:
+        vmin_io = vmin.clone() if vmin is not None else _f32(n, ref.device)
+    check(lib().dcq_range_to_scale(C.byref(step), n, ptr(vmax), ptr(vmin_io), int(ratio is not None),
+                                   float(ratio or 0.0), ptr(static_max), ptr(static_min), ptr(lin),
+                                   stream_of(ref.device)), "dcq_range_to_scale")
+    return lin, vmin_io
+
+
+def scale_level(rounding: Rounding, s: torch.Tensor, P: int, Q: int, *, reduce: bool, span: float) -> torch.Tensor:
+    """One scale level on s[P][Q] (modified in place when reducing); returns the level tensor [P]."""
+    level = _f32(P, s.device)
+    check(lib().dcq_scale_level(C.byref(rounding), ptr(s), P, Q, int(reduce), float(span), ptr(level),
+                                stream_of(s.device)), "dcq_scale_level")
+    return level
+
+
+def simple_round(rounding: Rounding, values: torch.Tensor) -> torch.Tensor:
+    """rounding(|values|) element-wise on a float32 tensor (scales are non-negative by construction)."""
+    flat = values.contiguous().view(-1)
+    return scale_level(rounding, flat, flat.numel(), 1, reduce=False, span=1.0).view(values.shape)
+
+
+def simple_round_signed(rounding: Rounding, values: torch.Tensor) -> torch.Tensor:
+    """rounding(values) element-wise on a float32 tensor of any sign (int / codebook / torch-dtype kinds)."""
+    _require_gpu(values)
+    flat = values.contiguous().view(-1)
+    out = torch.empty_like(flat)
+    check(lib().dcq_round_values(C.byref(rounding), ptr(flat), ptr(out), flat.numel(), stream_of(flat.device)),
+          "dcq_round_values")
+    return out.view(values.shape)
+
+
+def scale_join(a: torch.Tensor, b: torch.Tensor | None, *, fix_zero: bool) -> torch.Tensor:
+    out = torch.empty_like(a)
+    check(lib().dcq_scale_join(ptr(a), ptr(b), a.numel(), 1, int(fix_zero), ptr(out), stream_of(a.device)),
+          "dcq_scale_join")
+    return out
+
+
+def zero_point(step: Step, vmin: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    zero = torch.empty_like(scale)
+    check(lib().dcq_zero_point(C.byref(step), scale.numel(), ptr(vmin), ptr(scale), ptr(zero),
+                               stream_of(scale.device)), "dcq_zero_point")
+    return zero
+
+
+def quantize_groups(step: Step, x: torch.Tensor, scale, zero, *, outer=None, outer_lo=0.0, outer_hi=0.0,
+                    deq_clamp=False, deq_lo=0.0, deq_hi=0.0, out_dtype=None, want_dequant=True, want_codes=False):
+    _require_gpu(x)
+    G, S = x.shape
+    out_dtype = out_dtype or x.dtype
+    dq = torch.empty((G, S), dtype=out_dtype, device=x.device) if want_dequant else None
+    codes = torch.empty((G, S), dtype=torch.float32, device=x.device) if want_codes else None
+    check(lib().dcq_quantize_groups(C.byref(step), ptr(x), storage_of(x.dtype), G, S, ptr(scale), ptr(zero), ptr(outer),
+                                    outer_lo, outer_hi, int(deq_clamp), deq_lo, deq_hi, ptr(dq),
+                                    storage_of(out_dtype), ptr(codes), stream_of(x.device)), "dcq_quantize_groups")
+    return dq, codes
+
+
+def prescale_groups(x: torch.Tensor, outer: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
+    """clamp(x[g] / outer[g], lo, hi) as float32 [G][S]."""
+    _require_gpu(x)
+    G, S = x.shape
+    out = torch.empty((G, S), dtype=torch.float32, device=x.device)
+    check(lib().dcq_prescale_groups(ptr(x), storage_of(x.dtype), G, S, ptr(outer), lo, hi, ptr(out),
+                                    stream_of(x.device)), "dcq_prescale_groups")
+    return out
+
+
+def dequantize_groups(step: Step, codes: torch.Tensor, scale, zero, *, outer=None, deq_clamp=False, deq_lo=0.0,
+                      deq_hi=0.0, out_dtype=torch.float32) -> torch.Tensor:
+    _require_gpu(codes)
+    G, S = codes.shape
+    dq = torch.empty((G, S), dtype=out_dtype, device=codes.device)
+    check(lib().dcq_dequantize_groups(C.byref(step), ptr(codes), G, S, ptr(scale), ptr(zero), ptr(outer),
+                                      int(deq_clamp), deq_lo, deq_hi, ptr(dq), storage_of(out_dtype),
+                                      stream_of(codes.device)), "dcq_dequantize_groups")
+    return dq
+
+
+_pow_tables: dict[tuple[torch.device, torch.dtype, float], torch.Tensor] = {}
+
+
+def pow_table(device: torch.device, dtype: torch.dtype, degree: float) -> torch.Tensor:
+    """The 32768-entry table of ``x.pow_(degree)`` over all non-negative bit patterns of a 16-bit dtype."""
+    key = (device, dtype, float(degree))
+    if key not in _pow_tables:
+        table = torch.empty(32768, dtype=torch.int16, device=device)
+        check(lib().dcq_pow_table(storage_of(dtype), float(degree), ptr(table), stream_of(device)), "dcq_pow_table")
+        _pow_tables[key] = table
+    return _pow_tables[key]
+
+
+def range_search_groups(step: Step, w: torch.Tensor, ratios: list[float], degree: float, *, want_errors=False):
+    """w[G][S] -> dict(max, min | None, ratio, error[, errors[K][G]]) of float32 tensors."""
+    _require_gpu(w)
+    G, S = w.shape
+    dev = w.device
+    r = torch.tensor(ratios, dtype=torch.float64).to(torch.float32).to(dev)
+    zp = step.zero_domain != _lib.ZERO_NONE
+    out = dict(max=_f32(G, dev), min=_f32(G, dev) if zp else None, ratio=_f32(G, dev), error=_f32(G, dev))
+    errors = torch.empty((len(ratios), G), dtype=torch.float32, device=dev) if want_errors else None
+    table = pow_table(dev, w.dtype, degree) if w.dtype != torch.float32 else None
+    check(lib().dcq_range_search_groups(C.byref(step), ptr(w), storage_of(w.dtype), G, S, ptr(r), len(ratios),
+                                        float(degree), ptr(table), ptr(out["max"]), ptr(out["min"]),
+                                        ptr(out["ratio"]), ptr(out["error"]), ptr(errors), stream_of(dev)),
+          "dcq_range_search_groups")
+    if want_errors:
+        out["errors"] = errors
+    return out

@@ -1,0 +1,8 @@
+from .config import (BaseKeyEnableQuantKernelConfig, BaseQuantizerConfig, BaseQuantKernel, BaseQuantKernelConfig,
+                     DecomposedQuantizerConfig, ProgressiveQuantizerConfig, QuantizerConfig, QuantLowRankConfig)
+from .kernel import QuantRtnKernel
+from .processor import Quantizer
+
+__all__ = ["Quantizer", "QuantizerConfig", "ProgressiveQuantizerConfig", "DecomposedQuantizerConfig",
+           "BaseQuantizerConfig", "BaseQuantKernel", "BaseQuantKernelConfig", "BaseKeyEnableQuantKernelConfig",
+           "QuantLowRankConfig", "QuantRtnKernel"]

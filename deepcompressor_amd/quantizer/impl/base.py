@@ -1,0 +1,230 @@
+"""Fake-quantization driver (reference: deepcompressor/quantizer/impl/base.py:22-323).
+
+``QuantizerImpl.quantize`` has the reference's signature and results.  Two execution paths, both HIP:
+
+* fused   -- one step, one scale level, round-to-nearest: a single kernel reads the tensor once and writes
+             the dequantized tensor (and / or codes) once;
+* general -- multi-level scales, two progressive steps, explicit scales or a caller-supplied kernel object:
+             range kernel -> scale-tree kernels -> quantize / dequantize kernel.
+"""
+
+from __future__ import annotations
+
+import typing as tp
+from dataclasses import dataclass, field
+
+import torch
+
+from ... import engine
+from ...data.range import DynamicRange, QuantRange, RangeBound
+from ...data.scale import QuantScale
+from ...data.tensor import QuantTensor
+from ...data.zero import ZeroPointDomain
+from ...utils.config import KeyEnableConfig
+from ..config.base import BaseQuantizerConfig
+from ..config.kernel import BaseQuantKernel, BaseQuantKernelConfig
+from ..kernel.rtn import QuantRtnKernel
+from .info import QuantInfo
+
+__all__ = ["QuantizerImpl"]
+
+
+def _per_group(values: torch.Tensor, view_shape, n: int) -> torch.Tensor:
+    """A (#g0, 1, #g1, 1, ...) tensor (or a coarser one) as one contiguous value per group."""
+    keep = [v if i % 2 == 0 else 1 for i, v in enumerate(view_shape)]
+    if values.numel() == n:
+        return values.reshape(n).contiguous()
+    split = []
+    for d in range(0, values.ndim, 2):
+        split += [values.shape[d], keep[d] // values.shape[d]]
+    return values.view([v if i % 2 == 0 else 1 for i, v in enumerate(split)]).expand(split).reshape(n).contiguous()
+
+
+@dataclass
+class QuantizerImpl:
+    config: BaseQuantizerConfig | None
+    key: str = ""
+    info: QuantInfo | None = field(init=False, default=None)
+
+    def is_enabled(self) -> bool:
+        if self.config is None:
+            return False
+        if isinstance(self.config, KeyEnableConfig):
+            return self.config.is_enabled_for(self.key)
+        return self.config.is_enabled()
+
+    def quantize(self, tensor: torch.Tensor, *, kernel: BaseQuantKernel | BaseQuantKernelConfig | None = None,
+                 channels_dim: int | None = None, scale=None, zero: torch.Tensor | None = None, dynamic_range=None,
+                 range_bound: RangeBound | None = None, quant_range: QuantRange | None = None,
+                 return_with_dequant: bool = True, return_with_quant: bool = False,
+                 default_dtype: torch.dtype | None = torch.float16, develop_dtype: torch.dtype = torch.float32,
+                 **kwargs) -> QuantTensor:
+        shape = tensor.shape
+        if channels_dim is not None:
+            tensor = tensor.reshape(-1, *shape[channels_dim:])
+        round_delta = kwargs.pop("round_delta", None)
+        if round_delta is not None:
+            round_delta = round_delta.view(-1, *shape[channels_dim:])
+        result = self._quantize(tensor, kernel=kernel, scale=scale, zero=zero, dynamic_range=dynamic_range,
+                                range_bound=range_bound, quant_range=quant_range, round_delta=round_delta,
+                                return_with_dequant=return_with_dequant, return_with_quant=return_with_quant,
+                                default_dtype=default_dtype or tensor.dtype, develop_dtype=develop_dtype, **kwargs)
+        if result.data is not None:
+            result._dequantized = result.data.view(shape)
+        if result.qdata is not None:
+            result._quantized = result.qdata.view(shape)
+        return result
+
+    def _quantize(self, tensor: torch.Tensor, *, kernel=None, scale=None, zero=None, dynamic_range=None,
+                  range_bound=None, quant_range=None, round_delta=None, return_with_dequant: bool = True,
+                  return_with_quant: bool = False, default_dtype: torch.dtype = torch.float16,
+                  develop_dtype: torch.dtype = torch.float32, **kwargs) -> QuantTensor:
+        shape, dtype = tensor.shape, tensor.dtype
+        self.update(shape, default_dtype, quant_range, range_bound)
+        if self.info is None or self.info.num_steps == 0:
+            return QuantTensor(dequantized=tensor, quantized=tensor, view_shape=shape)
+        if develop_dtype != torch.float32:
+            raise NotImplementedError("the HIP kernels compute in float32 (develop_dtype=torch.float32)")
+        n_steps = self.info.num_steps
+        if n_steps > 2:
+            raise NotImplementedError("more than two progressive steps are not implemented")
+        # ---- normalise the per-step arguments
+        if scale is None:
+            scale = (None,) * n_steps
+        elif not isinstance(scale, tp.Sequence):
+            scale = (scale,)
+        if dynamic_range is None:
+            dynamic_range = (None,) * n_steps
+        elif isinstance(dynamic_range, DynamicRange):
+            dynamic_range = (dynamic_range,) if dynamic_range.is_set() else (None,) * n_steps
+        assert isinstance(scale, (tuple, list)) and len(scale) == n_steps, "scale must have one entry per step"
+        assert isinstance(dynamic_range, (tuple, list)) and len(dynamic_range) == n_steps, (
+            "dynamic_range must have one entry per step")
+        if isinstance(kernel, BaseQuantKernelConfig):
+            kernel = kernel.build()
+        native_rtn = kernel is None or type(kernel) is QuantRtnKernel
+        if native_rtn and round_delta is not None:
+            raise NotImplementedError("round_delta (learned rounding) is not implemented by the HIP kernels")
+        last = self.info.steps[-1]
+        dr_last = dynamic_range[-1]
+        fusable = (n_steps == 1 and native_rtn and scale[0] is None and last.scale.is_single_level()
+                   and not (dr_last is not None and dr_last.ratio is not None
+                            and (dr_last.max is not None or isinstance(dr_last.ratio, torch.Tensor))))
+        if fusable:
+            return self._quantize_fused(tensor, dr_last, return_with_dequant, return_with_quant)
+        return self._quantize_general(tensor, kernel, scale, zero, dynamic_range, round_delta, return_with_dequant,
+                                      return_with_quant, kwargs)
+
+    # ---- fused path --------------------------------------------------------------------------
+    def _quantize_fused(self, tensor, dyn, want_dequant, want_quant) -> QuantTensor:
+        step_info = self.info.steps[-1]
+        sinfo = step_info.scale
+        view = step_info.tensor_view_shape
+        keep = [v if i % 2 == 0 else 1 for i, v in enumerate(view)]
+        step = sinfo.native(tensor.device)
+        x2d, restore = engine.canonical_groups(tensor, view)
+        rmax = rmin = ratio = None
+        if dyn is not None:
+            if dyn.max is not None:
+                fmt = lambda v: DynamicRange._format_m_(  # noqa: E731
+                    v, shape=torch.Size(keep), dtype=torch.float32, device=tensor.device).contiguous().view(-1)
+                rmax = fmt(dyn.max)
+                rmin = fmt(dyn.min) if sinfo.has_zero_point else None
+            else:
+                ratio = dyn.ratio
+        both = want_dequant and want_quant
+        # with both outputs requested the reference hands back the *dequantized float32 values* as qdata
+        # (its qdata aliases the buffer it dequantizes in place); reproduce that, see QuantTensor docs
+        dq, codes, s, z = engine.fake_quant_fused(step, x2d, range_max=rmax, range_min=rmin, ratio=ratio,
+                                                  want_dequant=want_dequant, want_codes=want_quant)
+        scale = QuantScale().append(s.view(keep))
+        zero = z.view(keep) if sinfo.has_zero_point else torch.tensor(0, dtype=torch.float32, device=tensor.device)
+        quantized = None
+        if want_quant:
+            if both:
+                codes = engine.dequantize_groups(step, codes, s, z if sinfo.has_zero_point else None)
+            quantized = restore(codes)
+        return QuantTensor(dequantized=restore(dq) if want_dequant else None, quantized=quantized,
+                           scale=QuantScale().append(scale) if want_quant else None,
+                           zero=zero if want_quant else None, view_shape=view if want_quant else None)
+
+    # ---- general path ------------------------------------------------------------------------
+    def _quantize_general(self, tensor, kernel, scale, zero, dynamic_range, round_delta, want_dequant, want_quant,
+                          kwargs) -> QuantTensor:
+        info, shape, dtype, device = self.info, tensor.shape, tensor.dtype, tensor.device
+        n_steps = info.num_steps
+        quant_scale = QuantScale()
+        outer = outer_range = None  # previous step: per-group divisor (in the current step's group order) and clamp
+        outer_scale_data = None
+        for i, step_info in enumerate(info.steps):
+            sinfo = step_info.scale
+            n_groups = sinfo.num_groups
+            if outer_scale_data is not None:
+                outer = _per_group(outer_scale_data, step_info.tensor_view_shape, n_groups)
+            step_scale, step_zero = sinfo.quantize(scale=scale[i], zero=None if i < n_steps - 1 else zero,
+                                                   tensor=tensor, dynamic_range=dynamic_range[i], outer=outer,
+                                                   outer_range=outer_range)
+            quant_scale.append(step_scale)
+            if i < n_steps - 1:
+                outer_scale_data, outer_range = step_scale.data, step_info.tensor_quant_range
+        last = info.steps[-1]
+        sinfo, view = last.scale, last.tensor_view_shape
+        step = sinfo.native(device)
+        x2d, restore = engine.canonical_groups(tensor, view)
+        s = step_scale.data.contiguous().view(-1)
+        z = step_zero.contiguous().view(-1) if sinfo.has_zero_point else None
+        lo, hi = (outer_range.min, outer_range.max) if outer is not None else (0.0, 0.0)
+        clamp = False
+        deq_lo = deq_hi = 0.0
+        if outer is not None:
+            first = info.steps[0]
+            clamp = info.needs_dequant_saturation
+            deq_lo, deq_hi = first.quant_dtype.min_value, first.quant_dtype.max_value
+        native_rtn = kernel is None or type(kernel) is QuantRtnKernel
+        both = want_dequant and want_quant
+        dq = codes = None
+        if native_rtn:
+            dq, codes = engine.quantize_groups(step, x2d, s, z, outer=outer, outer_lo=lo, outer_hi=hi, deq_clamp=clamp,
+                                               deq_lo=deq_lo, deq_hi=deq_hi, out_dtype=dtype,
+                                               want_dequant=want_dequant, want_codes=want_quant)
+        else:
+            # caller-supplied kernel object: it receives the float32 working tensor of the last step
+            if outer is not None:
+                develop = restore(engine.prescale_groups(x2d, outer, lo, hi))
+            else:
+                develop = tensor.to(torch.float32) if dtype != torch.float32 else tensor.clone()
+            rd = None
+            if round_delta is not None:
+                rd = round_delta.view(1, 1, *view[2:]) if round_delta.shape[0] == 1 else round_delta.view(view)
+            codes_view = kernel.quantize(tensor=develop, view_shape=view, quant_dtype=last.quant_dtype,
+                                         zero_domain=last.zero_domain, scale=step_scale.data, zero=step_zero,
+                                         quant_range=last.quant_range, range_bound=last.range_bound, round_delta=rd,
+                                         **kwargs)
+            assert not codes_view.isnan().any(), "Quantized tensor contains NaN."
+            assert not codes_view.isinf().any(), "Quantized tensor contains Inf."
+            codes, _ = engine.canonical_groups(codes_view.reshape(shape), view)
+            if want_dequant:
+                dq = engine.dequantize_groups(step, codes, s, z, outer=outer, deq_clamp=clamp, deq_lo=deq_lo,
+                                              deq_hi=deq_hi, out_dtype=dtype)
+        quantized = None
+        if want_quant:
+            if both:  # the reference's qdata aliases its in-place float32 dequantization buffer
+                codes = engine.dequantize_groups(step, codes, s, z, outer=outer, deq_clamp=clamp, deq_lo=deq_lo,
+                                                 deq_hi=deq_hi, out_dtype=torch.float32)
+            quantized = restore(codes)
+        return QuantTensor(dequantized=restore(dq) if want_dequant else None, quantized=quantized,
+                           scale=quant_scale if want_quant else None, zero=step_zero if want_quant else None,
+                           view_shape=view if want_quant else None)
+
+    def update(self, tensor_shape: torch.Size, default_dtype: torch.dtype | None, quant_range: QuantRange | None,
+               range_bound: RangeBound | None) -> QuantInfo | None:
+        """(Re)build the plan when the config, shape, default dtype or ranges changed."""
+        if not self.is_enabled():
+            self.info = None
+            return None
+        config = self.config.decompose()
+        assert default_dtype is not None, "default_dtype must be set."
+        if self.info is None or self.info.is_outdated(config, tensor_shape, default_dtype, quant_range, range_bound):
+            self.info = QuantInfo.construct(config, tensor_shape, default_dtype, quant_range=quant_range,
+                                            range_bound=range_bound)
+        return self.info

@@ -1,0 +1,194 @@
+/*
+ * dcq.h -- C ABI of the MI355X (gfx950) calibration/quantization kernels.
+ *
+ * Every entry point takes plain device pointers, sizes and a HIP stream (passed as void*); nothing
+ * here allocates device memory, synchronises the host, or knows about torch.  All functions return
+ * DCQ_OK (0) or a negative dcq_status; dcq_last_error() gives the message of the calling thread's
+ * last failure.  Arithmetic is IEEE float32 exactly as the reference's develop_dtype=float32 path
+ * (true division, round-half-to-even, no fused multiply-add across reference ops).
+ *
+ * Layout convention ("canonical groups"): a tensor that the reference views as
+ * (#g0, gs0, #g1, gs1, ...) is handed over as x[G][S] with every quantization group contiguous,
+ * G = prod(#g_i), S = prod(gs_i).  For a 2-D weight with (1, g) groups this is the weight's own
+ * memory; other group shapes are permuted by the caller.
+ *
+ * Each declaration cites the reference code (paths relative to the reference repository) whose
+ * arithmetic it replaces.
+ */
+#ifndef DCQ_H_
+#define DCQ_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dcq_stream_t; /* hipStream_t */
+
+enum dcq_status {
+  DCQ_OK = 0,
+  DCQ_ERR_ARGUMENT = -1,    /* null pointer, bad size, misaligned buffer */
+  DCQ_ERR_UNSUPPORTED = -2, /* a combination the kernels do not implement (message says which) */
+  DCQ_ERR_HIP = -3          /* a HIP runtime call failed */
+};
+
+/* storage type of a tensor in memory */
+enum dcq_storage { DCQ_F32 = 0, DCQ_F16 = 1, DCQ_BF16 = 2 };
+
+/* deepcompressor/data/zero.py:9-13 */
+enum dcq_zero_domain { DCQ_ZERO_NONE = 0, DCQ_ZERO_PRE_SCALE = 1, DCQ_ZERO_POST_SCALE = 2 };
+
+/* How one value is snapped onto a data type: one call of simple_quantize
+ * (deepcompressor/quantizer/impl/simple.py:13-55). */
+enum dcq_round_kind {
+  DCQ_ROUND_F32 = 0,      /* torch.float32 scale dtype: identity                                     */
+  DCQ_ROUND_F16 = 1,      /* .to(float16).to(float32)                                  (simple.py:23-30) */
+  DCQ_ROUND_BF16 = 2,     /* .to(bfloat16).to(float32)                                                 */
+  DCQ_ROUND_INT = 3,      /* round half-to-even, clamp to [lo, hi]                      (simple.py:44-51) */
+  DCQ_ROUND_CODEBOOK = 4, /* clamp to [lo, hi], nearest codebook value, tie -> upper    (simple.py:37-43,
+                             csrc/quantize/quantize.cu:69-99)                                          */
+  DCQ_ROUND_EXP = 5       /* exp2(clamp(floor(log2 x), lo, hi))                         (simple.py:32-36) */
+};
+
+typedef struct dcq_rounding {
+  int32_t kind;          /* dcq_round_kind */
+  float lo, hi;          /* see dcq_round_kind */
+  const float* codebook; /* device pointer, ascending, codebook_size <= 256 (DCQ_ROUND_CODEBOOK only) */
+  int32_t codebook_size;
+  int32_t has_clamp;     /* optional extra clamp after rounding (the reference's quant_range for fp dtypes) */
+  float clamp_lo, clamp_hi;
+} dcq_rounding;
+
+/* One quantization step with a single-level group scale: the per-group arithmetic of
+ * QuantScaleInfo.quantize (deepcompressor/quantizer/impl/scale.py:142-242), rtn_quantize
+ * (quantizer/kernel/rtn.py:103-117) and the dequantization of QuantizerImpl._quantize
+ * (quantizer/impl/base.py:262-269). */
+typedef struct dcq_step {
+  dcq_rounding tensor; /* the quantization dtype with its (intersected) quant range */
+  dcq_rounding scale;  /* dtype of the group scale */
+  dcq_rounding zero;   /* dtype of the zero point (tensor dtype for PreScale, scale dtype for PostScale) */
+  int32_t zero_domain; /* dcq_zero_domain */
+  float q_span;        /* linear_tensor_quant_span: qmax - qmin with zero point, else qmax (scale.py:116-123) */
+  float q_min;         /* tensor_quant_range.min, used by the zero-point formula (scale.py:229-236) */
+  int32_t has_bound_min, has_bound_max; /* RangeBound (data/range.py:257-275) */
+  float bound_min, bound_max;
+} dcq_step;
+
+const char* dcq_version(void);
+const char* dcq_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Codebook rounding.  Replaces _C.round_to_nearest_in_codebook_cuda(tensor, codebook, inplace, bnb)
+ * (deepcompressor/csrc/pybind.cpp:6-10, csrc/quantize/quantize.cu:104-160) called from
+ * Codebook.round (data/codebook.py:37-50).  y may alias x.  x, y: n values of `storage` type.
+ * The reference's `bnb` variant is never selected by its own callers and is not provided.
+ * ------------------------------------------------------------------------------------------- */
+int dcq_round_to_codebook(const void* x, void* y, int64_t n, int32_t storage, const float* codebook,
+                          int32_t codebook_size, dcq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused fake quantization of x[G][S], one scale (and zero) per group: range measurement ->
+ * scale / zero -> round-to-nearest codes -> dequantization, one read and one write of the tensor.
+ * Replaces the chain DynamicRange.measure (data/range.py:277-356) -> QuantScaleInfo.quantize
+ * (quantizer/impl/scale.py:142-242) -> rtn_quantize (quantizer/kernel/rtn.py:68-117) -> dequant
+ * (quantizer/impl/base.py:262-279) that Quantizer.quantize (quantizer/processor.py:93-183) runs for
+ * a single-step, single-scale-level config.
+ *
+ *   range_max/range_min : optional static per-group range [G] (DynamicRange with max set, ratio None);
+ *                         NULL -> measured from x.  range_min is ignored without a zero point.
+ *   has_ratio/ratio     : DynamicRange.ratio applied to the measured range.
+ *   dequant             : optional output, `storage` type, same layout as x.
+ *   codes               : optional output, float32 integer/codebook values (the reference's qdata).
+ *   scale, zero         : optional outputs [G] float32 (zero is all 0 without a zero point).
+ * ------------------------------------------------------------------------------------------- */
+int dcq_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
+                          const float* range_max, const float* range_min, int32_t has_ratio, float ratio,
+                          void* dequant, float* codes, float* scale, float* zero, dcq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Building blocks of the general path (multi-level scales, progressive two-step configs, custom
+ * quantization kernels).  Same references as above, one reference op chain per function.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Per-group range of x[G][S]: max|x| (zero_domain NONE) or (max, min).  When `outer` is given the
+ * measured value is clamp(x / outer[g], outer_lo, outer_hi), i.e. the un-rounded output of a previous
+ * progressive step (quantizer/impl/base.py:221-224).  data/range.py:309-322. */
+int dcq_group_range(const void* x, int32_t storage, int64_t G, int64_t S, int32_t zero_domain,
+                    const float* outer, float outer_lo, float outer_hi, float* vmax, float* vmin,
+                    dcq_stream_t stream);
+
+/* ratio, PreScale clamp, static bound, RangeBound, span / q_span -> un-quantized linear scale [n];
+ * vmin is updated in place to the range minimum the zero point must use.
+ * data/range.py:330-355, quantizer/impl/scale.py:173-188. */
+int dcq_range_to_scale(const dcq_step* step, int64_t n, const float* vmax, float* vmin, int32_t has_ratio,
+                       float ratio, const float* static_max, const float* static_min, float* linear_scale,
+                       dcq_stream_t stream);
+
+/* One level of quantize_scale (quantizer/impl/scale.py:46-62) on s[P][Q] (Q children per parent):
+ *   reduce != 0: level[p] = Q(max_q s[p][q] / span), s[p][q] /= level[p]   (non-last level, or last level with Q > 1)
+ *   reduce == 0: level[i] = Q(s[i])                                        (last level, one scale per group)
+ * s must hold non-negative values (the caller passes |linear scale|; this function takes fabsf first). */
+int dcq_scale_level(const dcq_rounding* rounding, float* s, int64_t P, int64_t Q, int32_t reduce, float span,
+                    float* level, dcq_stream_t stream);
+
+/* out[i] = Q(in[i]) for values of any sign: simple_quantize (quantizer/impl/simple.py:13-55) on a float32 array. */
+int dcq_round_values(const dcq_rounding* rounding, const float* in, float* out, int64_t n, dcq_stream_t stream);
+
+/* compound[i] = a[i] * b[i / Q] with zeros replaced by 1 when fix_zero (data/scale.py:66-69,91-117). */
+int dcq_scale_join(const float* a, const float* b, int64_t n, int64_t Q, int32_t fix_zero, float* compound,
+                   dcq_stream_t stream);
+
+/* zero[i] = Q(q_min - vmin[i] / scale[i]) (PreScale) or Q(q_min * scale[i] - vmin[i]) (PostScale).
+ * quantizer/impl/scale.py:229-236. */
+int dcq_zero_point(const dcq_step* step, int64_t n, const float* vmin, const float* scale, float* zero,
+                   dcq_stream_t stream);
+
+/* rtn_quantize (quantizer/kernel/rtn.py:103-117) + dequantization (quantizer/impl/base.py:262-279) of
+ * x[G][S] with given per-group scale / zero.  `outer` as in dcq_group_range; with it the dequantized
+ * value is clamped to [deq_lo, deq_hi] when deq_clamp (needs_dequant_saturation) and multiplied back.
+ * x may be float32 working data (storage DCQ_F32) while dequant is written as `out_storage`. */
+int dcq_quantize_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
+                        const float* scale, const float* zero, const float* outer, float outer_lo, float outer_hi,
+                        int32_t deq_clamp, float deq_lo, float deq_hi, void* dequant, int32_t out_storage,
+                        float* codes, dcq_stream_t stream);
+
+/* out[g][i] = clamp(x[g][i] / outer[g], lo, hi) in float32: the working tensor a progressive step hands to the next
+ * one (quantizer/impl/base.py:221-224); only needed when a caller-supplied kernel object must see that tensor. */
+int dcq_prescale_groups(const void* x, int32_t storage, int64_t G, int64_t S, const float* outer, float lo, float hi,
+                        float* out, dcq_stream_t stream);
+
+/* Dequantize given codes[G][S] (float32), e.g. those returned by a GPTQ kernel: same arithmetic as above. */
+int dcq_dequantize_groups(const dcq_step* step, const float* codes, int64_t G, int64_t S, const float* scale,
+                          const float* zero, const float* outer, int32_t deq_clamp, float deq_lo, float deq_hi,
+                          void* dequant, int32_t out_storage, dcq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Range-ratio grid search, all candidates per group in one pass over the weights.
+ * Replaces the ask/tell loop of DynamicRangeCalibrator (deepcompressor/calib/range.py:73-221) as
+ * driven by SearchBasedCalibrator._calibrate_wgts with the TensorError objective and Group
+ * granularity (calib/search.py:776-790), clamp-based (static weights, calib/range.py:69-71).
+ *
+ * dcq_pow_table: table[i] = storage(pow(value_of_bits(i), degree)) for the 32768 non-negative 16-bit
+ * patterns of `storage` (F16 or BF16), reproducing Tensor.pow_(degree) of the torch CPU backend on
+ * that dtype (exponent rounded to the dtype first; bf16 special cases 2 and 3).  calib/search.py:781.
+ *
+ * dcq_range_search_groups: for each group g of w[G][S] and each ratio k (in the given order, the
+ * reference's is [1.0, then descending]): candidate range = base range * ratio (data/range.py:358-395),
+ * fake-quantize with that static range, error = sum over the group of |Q(w) - w|^degree evaluated in
+ * the weight's storage type in the summation order of the torch CPU backend, keep the first strictly
+ * smallest.  Outputs [G]: best_max, best_min (NULL without zero point), best_ratio (float32 of the
+ * ratio), best_error (storage type, as float32 values); errors (optional, [K][G] float32 values).
+ * S must be a multiple of 16 (16-bit storage) or 8 (float32) and at most 512.
+ * ------------------------------------------------------------------------------------------- */
+int dcq_pow_table(int32_t storage, double degree, uint16_t* table, dcq_stream_t stream);
+
+int dcq_range_search_groups(const dcq_step* step, const void* w, int32_t storage, int64_t G, int64_t S,
+                            const float* ratios, int32_t K, double degree, const uint16_t* pow_table,
+                            float* best_max, float* best_min, float* best_ratio, float* best_error, float* errors,
+                            dcq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCQ_H_ */

@@ -1,0 +1,106 @@
+"""HIP fake-quantization (through the C ABI) against the reference fixtures and the oracle -- bit-exact."""
+
+import numpy as np
+import pytest
+import torch
+from _product import build_quantizer, to_device, to_np
+from conftest import assert_bit_equal, load_golden
+
+import quant_oracle as qo
+from deepcompressor_amd.data.range import DynamicRange
+
+pytestmark = pytest.mark.gpu
+FQ = load_golden("fake_quant")
+
+
+def _leaves(qt):
+    return list(qt.scale.state_dict("s").values())
+
+
+@pytest.mark.parametrize("tag", sorted(FQ.meta["entries"]))
+def test_fake_quant_golden(tag):
+    e = FQ.meta["entries"][tag]
+    case = FQ.meta["cases"][e["case"]]
+    w = to_device(FQ[f"{tag}|x"], e["in_dtype"])
+    q = build_quantizer(case)
+    kw = {}
+    if e["dyn"] is not None:
+        kw["dynamic_range"] = DynamicRange(ratio=e["dyn"]["ratio"])
+    codes = q.quantize(w, return_with_dequant=False, return_with_quant=True, **kw)
+    deq = q.quantize(w, return_with_dequant=True, return_with_quant=False, **kw)
+    assert list(codes.view_shape) == e["view_shape"]
+    assert deq.data.dtype == w.dtype and deq.data.shape == w.shape
+    assert_bit_equal(to_np(codes.scale.data), FQ[f"{tag}|scale"], "compound scale")
+    leaves = _leaves(codes)
+    assert len(leaves) == e["n_leaves"]
+    for i, leaf in enumerate(leaves):
+        assert_bit_equal(to_np(leaf), FQ[f"{tag}|leaf{i}"], f"scale leaf {i}")
+    want_zero = FQ[f"{tag}|zero"]
+    assert_bit_equal(np.broadcast_to(to_np(codes.zero), want_zero.shape), want_zero, "zero")
+    assert_bit_equal(to_np(codes.qdata), FQ[f"{tag}|codes"], "codes")
+    assert_bit_equal(to_np(deq.data), FQ[f"{tag}|dequant"], "dequant")
+
+
+@pytest.mark.parametrize("cname", ["sint4_g128_f16s", "uint4_post_g128_f16s", "uint4_pre_g128_f16s", "qoq_g128",
+                                   "nvfp4_g16", "sint8_gchn_f16s", "sint4_2x64"])
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_fake_quant_vs_oracle_random(cname, dt):
+    """Fresh seeded inputs (not in the fixtures), larger shapes, against the CPU oracle."""
+    case = FQ.meta["cases"][cname]
+    g = torch.Generator().manual_seed(1234)
+    w = (torch.randn(256, 1024, generator=g) * 0.05)
+    w[3] = 0
+    w[5, 7] = 3.0
+    wt = w.to({"bf16": torch.bfloat16, "f16": torch.float16}[dt])
+    want = qo.fake_quantize(wt.float().numpy(), dt, qo.spec_from_case(case))
+    q = build_quantizer(case)
+    wd = wt.cuda()
+    codes = q.quantize(wd, return_with_dequant=False, return_with_quant=True)
+    deq = q.quantize(wd)
+    assert_bit_equal(to_np(codes.scale.data), want["scale"], "scale")
+    assert_bit_equal(to_np(codes.qdata), want["codes"], "codes")
+    assert_bit_equal(to_np(deq.data), want["dequant"], "dequant")
+
+
+def test_static_range_and_explicit_scale_roundtrip():
+    """A stored (min, max) range and a stored scale/zero reproduce the same codes (load_state_dict use)."""
+    case = FQ.meta["cases"]["uint4_post_g128_f16s"]
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(64, 512, generator=g) * 0.03).to(torch.bfloat16).cuda()
+    q = build_quantizer(case)
+    base = q.quantize(w, return_with_dequant=False, return_with_quant=True)
+    info = q.update(w.shape, default_dtype=torch.bfloat16)
+    view = info.steps[-1].tensor_view_shape
+    from deepcompressor_amd import engine
+    x2d, _ = engine.canonical_groups(w, view)
+    vmax, vmin = engine.group_range(x2d, with_min=True)
+    keep = [v if i % 2 == 0 else 1 for i, v in enumerate(view)]
+    again = q.quantize(w, return_with_dequant=False, return_with_quant=True,
+                       dynamic_range=DynamicRange(min=vmin.view(keep), max=vmax.view(keep)))
+    assert torch.equal(again.qdata, base.qdata) and torch.equal(again.scale.data, base.scale.data)
+    given = q.quantize(w, return_with_dequant=False, return_with_quant=True, scale=base.scale.data, zero=base.zero)
+    assert torch.equal(given.qdata, base.qdata)
+    # both outputs requested: qdata carries the float32 dequantized values (reference behaviour)
+    both = q.quantize(w, return_with_dequant=True, return_with_quant=True)
+    assert torch.equal(both.qdata.to(torch.bfloat16), both.data)
+
+
+def test_empty_and_cpu_inputs_fail_loudly():
+    case = FQ.meta["cases"]["sint4_g128_f16s"]
+    q = build_quantizer(case)
+    with pytest.raises(Exception, match="GPU"):
+        q.quantize(torch.zeros(4, 128, dtype=torch.bfloat16))
+
+
+def test_codebook_round_matches_oracle():
+    from deepcompressor_amd.data.dtype import QuantDataType
+    g = torch.Generator().manual_seed(0)
+    for name in ("sfp4_e2m1_all", "sfp8_e4m3_nan", "sfp6_e3m2_all"):
+        d = QuantDataType.from_str(name)
+        x = torch.randn(100_003, generator=g) * d.max_value / 2
+        cb = qo.QDtype.parse(name).codebook()
+        # exact midpoints between neighbouring values exercise the tie rule
+        mids = torch.from_numpy((cb[:-1] + cb[1:]) / 2)
+        x = torch.cat([x, mids, torch.from_numpy(cb)])
+        got = d.get_codebook(device="cuda").round(x.cuda())
+        assert_bit_equal(to_np(got), qo.codebook_round(x.numpy(), cb), name)
