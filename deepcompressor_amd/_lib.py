@@ -67,6 +67,9 @@ _SIGNATURES = {
     "dcq_prescale_groups": [_p, _i32, _i64, _i64, _p, _f, _f, _p, _p],
     "dcq_dequantize_groups": [C.POINTER(Step), _p, _i64, _i64, _p, _p, _p, _i32, _f, _f, _p, _i32, _p],
     "dcq_pow_table": [_i32, _d, _p, _p],
+    "dcq_hessian_accumulate": [_p, _i32, _i64, _i64, _f, _p, _p, _i64, _p],
+    "dcq_gptq_sweep_block": [C.POINTER(Step), _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _f, _i32, _i32, _i32, _p,
+                             _p, _p, _p],
     "dcq_range_search_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _i32, _d, _p, _p, _p, _p, _p, _p, _p],
 }
 _lib = None
@@ -85,6 +88,8 @@ def lib():
         for name, sig in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes, fn.restype = sig, C.c_int
+        handle.dcq_hessian_workspace_bytes.argtypes = [_i64, _i64]
+        handle.dcq_hessian_workspace_bytes.restype = C.c_int64
         handle.dcq_version.restype = C.c_char_p
         handle.dcq_last_error.restype = C.c_char_p
         _lib = handle

@@ -1,0 +1,520 @@
+// GPTQ kernels (gfx950): Hessian accumulation H += alpha * X^T X on the matrix cores, and the
+// column sweep of one 128-column block (quantize, propagate the error inside the block).
+//
+// Hessian.  X is [T][C] 16-bit, row-major (tokens x channels).  Both MFMA operands of X^T X need 8
+// consecutive *tokens* of one channel per lane, so X is first transposed once into a zero-padded
+// Xt[Cp][Tp] (a pure copy, ~2 passes over X against ~C/64 passes of arithmetic); the contraction is
+// then the standard "A [M][K] times B [N][K] transposed" form with both fragments contiguous 16-byte
+// LDS reads.  Products of 16-bit inputs are exact in float32, accumulation is float32.  Only tiles
+// on or above the diagonal are computed and mirrored.  K (=tokens) is split over several workgroups
+// when the tile count alone cannot fill the chip; partial tiles go to a workspace slab and are
+// summed in a fixed order, so the result is bitwise reproducible.
+//
+// Sweep.  Rows of W are independent in GPTQ.  A team of 16 lanes owns one row of the 128-column
+// block (8 columns per lane, in registers); the upper-triangular 128x128 block of U (U^T U = H^-1)
+// sits in LDS.  For each column the owner lane quantizes, the error is broadcast inside the team and
+// every lane updates its remaining columns.
+#include "dcq_common.cuh"
+
+namespace dcq {
+
+// =============================================================================================
+// transpose + pad
+// =============================================================================================
+constexpr int kTrTile = 64;
+
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* __restrict__ x, int64_t T, int64_t C,
+                                                            uint16_t* __restrict__ xt, int64_t Tp) {
+  __shared__ uint16_t tile[kTrTile][kTrTile + 2];
+  const int64_t t0 = static_cast<int64_t>(blockIdx.x) * kTrTile;
+  const int64_t c0 = static_cast<int64_t>(blockIdx.y) * kTrTile;
+  // load: 64 rows (tokens) x 64 channels, 8 channels (16 B) per thread, 32 rows per pass
+  const int lr = threadIdx.x / 8, lc = (threadIdx.x % 8) * 8;
+  const bool vec_ok = (C % 8) == 0;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = lr + pass * 32;
+    const int64_t t = t0 + r;
+    uint16_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t < T) {
+      if (vec_ok && c0 + lc + 8 <= C) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(x + t * C + c0 + lc);
+        const uint16_t* pr = reinterpret_cast<const uint16_t*>(&raw);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = pr[i];
+      } else {
+        for (int i = 0; i < 8; ++i)
+          if (c0 + lc + i < C) v[i] = x[t * C + c0 + lc + i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tile[r][lc + i] = v[i];
+  }
+  __syncthreads();
+  // store: 64 channels x 64 tokens, 8 tokens (16 B) per thread
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = lr + pass * 32;
+    uint4 raw;
+    uint16_t* pr = reinterpret_cast<uint16_t*>(&raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pr[i] = tile[lc + i][c];
+    *reinterpret_cast<uint4*>(xt + (c0 + c) * Tp + t0 + lc) = raw;
+  }
+}
+
+// =============================================================================================
+// SYRK on MFMA: tile 128 x 128, K step 64, 4 waves (2 x 2), 32x32x16 instructions
+// =============================================================================================
+constexpr int kTile = 128;
+constexpr int kBK = 64;
+constexpr int kChunks = kBK / 8;                      // 16-byte k-chunks per row
+constexpr int kChunkStride = kTile * 16 + 16;         // bytes: 128 rows x 16 B, +16 so chunk columns shift 4 banks
+constexpr int kOperandBytes = kChunks * kChunkStride;  // one operand tile in LDS
+constexpr int kSyrkThreads = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int ST>
+__device__ __forceinline__ f32x16 mfma_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
+  if constexpr (ST == DCQ_BF16) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+                                                  0);
+  }
+}
+
+struct SyrkParams {
+  const uint16_t* xt;  // [Cp][Tp]
+  int64_t Tp;
+  int32_t C, Cp;
+  int32_t tiles_per_side;  // Cp / 128
+  int32_t num_tiles;       // upper triangle incl. diagonal
+  int32_t splits;          // K splits
+  int32_t ktiles_per_split;
+  float alpha;
+  float* H;        // [C][C]
+  float* partial;  // [splits][num_tiles][128*128] when splits > 1
+};
+
+__device__ __forceinline__ void tile_coords(int idx, int n, int& bi, int& bj) {
+  // row-major enumeration of the upper triangle: row bi has n - bi tiles
+  int row = 0, rem = idx;
+  while (rem >= n - row) {
+    rem -= n - row;
+    ++row;
+  }
+  bi = row;
+  bj = row + rem;
+}
+
+template <int ST>
+__global__ __launch_bounds__(kSyrkThreads, 2) void syrk_kernel(const SyrkParams p) {
+  extern __shared__ __align__(16) unsigned char lds[];  // [2 buffers][A, B][kOperandBytes]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;  // wave's 64 x 64 quadrant
+  const int tile_idx = blockIdx.x % p.num_tiles;
+  const int split = blockIdx.x / p.num_tiles;
+  int bi, bj;
+  tile_coords(tile_idx, p.tiles_per_side, bi, bj);
+  const bool diag = bi == bj;
+
+  // staging map: thread -> (row, chunk) pieces of a 128 x 64 operand tile; 1024 pieces / 256 threads = 4 each
+  // piece id = it * 256 + tid; row = id / 8, chunk = id % 8  (8 consecutive lanes read one full 128-byte line)
+  const uint16_t* a_base = p.xt + static_cast<int64_t>(bi) * kTile * p.Tp;
+  const uint16_t* b_base = p.xt + static_cast<int64_t>(bj) * kTile * p.Tp;
+  const int64_t k_begin = static_cast<int64_t>(split) * p.ktiles_per_split * kBK;
+  int64_t k_end = k_begin + static_cast<int64_t>(p.ktiles_per_split) * kBK;
+  if (k_end > p.Tp) k_end = p.Tp;
+  const int nk = static_cast<int>((k_end - k_begin) / kBK);
+
+  uint4 ra[4], rb[4];
+  auto load_tile = [&](int kt) {
+    const int64_t k0 = k_begin + static_cast<int64_t>(kt) * kBK;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int id = it * kSyrkThreads + tid;
+      const int row = id >> 3, chunk = id & 7;
+      ra[it] = *reinterpret_cast<const uint4*>(a_base + static_cast<int64_t>(row) * p.Tp + k0 + chunk * 8);
+      if (!diag) rb[it] = *reinterpret_cast<const uint4*>(b_base + static_cast<int64_t>(row) * p.Tp + k0 + chunk * 8);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* a_lds = lds + buf * 2 * kOperandBytes;
+    unsigned char* b_lds = a_lds + kOperandBytes;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int id = it * kSyrkThreads + tid;
+      const int row = id >> 3, chunk = id & 7;
+      *reinterpret_cast<uint4*>(a_lds + chunk * kChunkStride + row * 16) = ra[it];
+      if (!diag) *reinterpret_cast<uint4*>(b_lds + chunk * kChunkStride + row * 16) = rb[it];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  const int frag_row = lane & 31, frag_half = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const unsigned char* a_lds = lds + buf * 2 * kOperandBytes;
+    const unsigned char* b_lds = diag ? a_lds : a_lds + kOperandBytes;
+#pragma unroll
+    for (int ks = 0; ks < kBK / 16; ++ks) {
+      const int chunk = ks * 2 + frag_half;
+      uint4 af[2], bf[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        af[m] = *reinterpret_cast<const uint4*>(a_lds + chunk * kChunkStride + (wr * 64 + m * 32 + frag_row) * 16);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        bf[n] = *reinterpret_cast<const uint4*>(b_lds + chunk * kChunkStride + (wc * 64 + n * 32 + frag_row) * 16);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = mfma_32x32x16<ST>(af[m], bf[n], acc[m][n]);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue.  C/D layout of the 32x32 instruction: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int col_in = lane & 31, row_off = 4 * (lane >> 5);
+  if (p.splits > 1) {
+    float* slab = p.partial + (static_cast<int64_t>(split) * p.num_tiles + tile_idx) * (kTile * kTile);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + row_off;
+          const int col = wc * 64 + n * 32 + col_in;
+          slab[row * kTile + col] = acc[m][n][r];
+        }
+    return;
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = bi * kTile + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + row_off;
+        const int col = bj * kTile + wc * 64 + n * 32 + col_in;
+        if (row < p.C && col < p.C) {
+          const float v = p.alpha * acc[m][n][r];
+          if (!diag || col >= row) {
+            float* h = p.H + static_cast<int64_t>(row) * p.C + col;
+            const float sum = *h + v;
+            *h = sum;
+            if (col != row) p.H[static_cast<int64_t>(col) * p.C + row] = sum;
+          }
+        }
+      }
+}
+
+// H[tile] += alpha * sum_s partial[s][tile]  (fixed order), mirrored
+__global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkParams p) {
+  const int tile_idx = blockIdx.x;
+  int bi, bj;
+  tile_coords(tile_idx, p.tiles_per_side, bi, bj);
+  for (int e = threadIdx.x; e < kTile * kTile; e += 256) {
+    const int r = e / kTile, c = e % kTile;
+    const int row = bi * kTile + r, col = bj * kTile + c;
+    if (row >= p.C || col >= p.C) continue;
+    if (bi == bj && col < row) continue;
+    float s = 0.0f;
+    for (int sp = 0; sp < p.splits; ++sp)
+      s = s + p.partial[(static_cast<int64_t>(sp) * p.num_tiles + tile_idx) * (kTile * kTile) + e];
+    float* h = p.H + static_cast<int64_t>(row) * p.C + col;
+    const float sum = *h + p.alpha * s;
+    *h = sum;
+    if (col != row) p.H[static_cast<int64_t>(col) * p.C + row] = sum;
+  }
+}
+
+static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct HessianPlan {
+  int64_t Cp, Tp;
+  int tiles_side, num_tiles, splits, ktiles_per_split;
+  size_t xt_bytes, partial_bytes;
+};
+
+static HessianPlan plan_hessian(int64_t T, int64_t C) {
+  HessianPlan h;
+  h.Cp = round_up(C, kTile);
+  h.Tp = round_up(T, kBK);
+  h.tiles_side = static_cast<int>(h.Cp / kTile);
+  h.num_tiles = h.tiles_side * (h.tiles_side + 1) / 2;
+  const int ktiles = static_cast<int>(h.Tp / kBK);
+  // two workgroups fit per CU: aim for >= 4 rounds of 512 resident workgroups, keep >= 32 k-tiles per split
+  int splits = 1;
+  while (static_cast<int64_t>(h.num_tiles) * splits < 2048 && ktiles / (splits * 2) >= 32 && splits < 64) splits *= 2;
+  h.splits = splits;
+  h.ktiles_per_split = (ktiles + splits - 1) / splits;
+  h.xt_bytes = static_cast<size_t>(h.Cp) * h.Tp * 2;
+  h.partial_bytes = splits > 1 ? static_cast<size_t>(splits) * h.num_tiles * kTile * kTile * 4 : 0;
+  return h;
+}
+
+// =============================================================================================
+// GPTQ column sweep of one block
+// =============================================================================================
+constexpr int kSweepCols = 128;     // columns per block (the reference's block_size)
+constexpr int kSweepTeam = 16;      // lanes per row
+constexpr int kSweepPerLane = 8;    // columns per lane
+constexpr int kSweepThreads = 512;  // 8 waves = 32 rows per workgroup
+
+struct SweepParams {
+  dcq_step step;
+  float* W;        // [R][ldw], columns already permuted; only read here
+  int64_t ldw;
+  const float* U;  // [C][C] upper triangular, permuted order
+  int64_t C;
+  int64_t R;
+  int32_t c0, bc;       // block start / width (<= 128)
+  const float* scale;   // [row_groups][col_groups]
+  const float* zero;    // same shape, or NULL when zero_scalar applies
+  float zero_scalar;
+  int32_t row_group_size, col_group_size, col_groups;
+  const int64_t* perm;  // [C] original column of each permuted column
+  int32_t has_bound_min, has_bound_max;
+  float bound_min, bound_max;
+  float* Q;    // [R][ldw] codes, permuted order
+  float* Err;  // [R][128]
+};
+
+template <int ZD, bool INT_Q>
+__global__ __launch_bounds__(kSweepThreads) void gptq_sweep_kernel(const SweepParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* u_lds = reinterpret_cast<float*>(smem);           // [128][128], rows >= bc / cols >= bc zero
+  float* cb = u_lds + kSweepCols * kSweepCols;             // tensor codebook [256]
+  // stage the diagonal block of U (only the upper triangle is ever read)
+  for (int e = threadIdx.x; e < kSweepCols * kSweepCols; e += kSweepThreads) {
+    const int r = e / kSweepCols, c = e % kSweepCols;
+    float v = 0.0f;
+    if (r < p.bc && c < p.bc && c >= r) v = p.U[(p.c0 + r) * p.C + p.c0 + c];
+    u_lds[e] = v;
+  }
+  if (!INT_Q)
+    for (int i = threadIdx.x; i < p.step.tensor.codebook_size; i += kSweepThreads) cb[i] = p.step.tensor.codebook[i];
+  __syncthreads();
+
+  const int tl = threadIdx.x & (kSweepTeam - 1);
+  const int team = threadIdx.x / kSweepTeam;
+  const int teams_per_block = kSweepThreads / kSweepTeam;
+  const dcq_step& st = p.step;
+  for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * teams_per_block; row0 < p.R;
+       row0 += static_cast<int64_t>(gridDim.x) * teams_per_block) {
+    const int64_t row = row0 + team;
+    const bool live = row < p.R;
+    const int64_t rr = live ? row : 0;
+    float w[kSweepPerLane], s[kSweepPerLane], z[kSweepPerLane], q[kSweepPerLane], er[kSweepPerLane];
+    const int64_t rg = rr / p.row_group_size;
+#pragma unroll
+    for (int i = 0; i < kSweepPerLane; ++i) {
+      const int col = tl * kSweepPerLane + i;
+      const bool in = col < p.bc;
+      w[i] = in ? p.W[rr * p.ldw + p.c0 + col] : 0.0f;
+      const int64_t cg = in ? p.perm[p.c0 + col] / p.col_group_size : 0;
+      s[i] = p.scale[rg * p.col_groups + cg];
+      z[i] = ZD == DCQ_ZERO_NONE ? 0.0f : (p.zero ? p.zero[rg * p.col_groups + cg] : p.zero_scalar);
+      q[i] = 0.0f;
+      er[i] = 0.0f;
+    }
+    for (int owner = 0; owner < kSweepTeam; ++owner) {
+      if (owner * kSweepPerLane >= p.bc) break;  // uniform
+#pragma unroll
+      for (int i = 0; i < kSweepPerLane; ++i) {
+        const int c = owner * kSweepPerLane + i;
+        if (c < p.bc) {  // uniform
+          // every lane evaluates its own slot i; only the owner's value is used
+          float x = w[i];
+          if (p.has_bound_min) x = fmaxf(x, p.bound_min);
+          if (p.has_bound_max) x = fminf(x, p.bound_max);
+          const float t = to_code_input<ZD>(x, s[i], z[i]);
+          const float qi = INT_Q ? round_int(t, st.tensor.lo, st.tensor.hi) : apply_rounding(st.tensor, t, cb);
+          const float d = from_code<ZD>(qi, s[i], z[i]);
+          const float ucc = u_lds[c * kSweepCols + c];
+          const float e_own = (w[i] - d) / ucc;
+          if (tl == owner) {
+            q[i] = qi;
+            er[i] = e_own;
+          }
+          const float e = __shfl(e_own, owner, kSweepTeam);
+          if (tl >= owner) {
+            const float4 u0 = *reinterpret_cast<const float4*>(u_lds + c * kSweepCols + tl * kSweepPerLane);
+            const float4 u1 = *reinterpret_cast<const float4*>(u_lds + c * kSweepCols + tl * kSweepPerLane + 4);
+            const float uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+            for (int k = 0; k < kSweepPerLane; ++k) {
+              // columns <= c of the owner lane see u = 0 below the diagonal except the diagonal itself,
+              // whose update is harmless (that column is finished)
+              w[k] = w[k] - e * uu[k];
+            }
+          }
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < kSweepPerLane; ++i) {
+        const int col = tl * kSweepPerLane + i;
+        if (col < p.bc) p.Q[row * p.ldw + p.c0 + col] = q[i];
+        p.Err[row * kSweepCols + col] = col < p.bc ? er[i] : 0.0f;
+      }
+    }
+  }
+}
+
+}  // namespace dcq
+
+using namespace dcq;
+
+extern "C" {
+
+int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C) {
+  if (T <= 0 || C <= 0) return 0;
+  const HessianPlan h = plan_hessian(T, C);
+  return static_cast<int64_t>(round_up(static_cast<int64_t>(h.xt_bytes), 256) + h.partial_bytes);
+}
+
+int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C, float alpha, float* H, void* workspace,
+                           int64_t workspace_bytes, dcq_stream_t stream) {
+  DCQ_REQUIRE(T >= 0 && C > 0, DCQ_ERR_ARGUMENT, "bad sizes T=%lld C=%lld", (long long)T, (long long)C);
+  if (T == 0) return DCQ_OK;
+  DCQ_REQUIRE(x && H && workspace, DCQ_ERR_ARGUMENT, "NULL buffer");
+  DCQ_REQUIRE(storage == DCQ_F16 || storage == DCQ_BF16, DCQ_ERR_UNSUPPORTED,
+              "Hessian accumulation takes float16 / bfloat16 activations");
+  DCQ_REQUIRE(C < (1 << 20), DCQ_ERR_UNSUPPORTED, "C too large");
+  DCQ_REQUIRE((reinterpret_cast<uintptr_t>(x) & 1u) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0,
+              DCQ_ERR_ARGUMENT, "workspace must be 256-byte aligned");
+  const HessianPlan h = plan_hessian(T, C);
+  DCQ_REQUIRE(workspace_bytes >= dcq_hessian_workspace_bytes(T, C), DCQ_ERR_ARGUMENT,
+              "workspace too small: %lld < %lld bytes", (long long)workspace_bytes,
+              (long long)dcq_hessian_workspace_bytes(T, C));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint16_t* xt = static_cast<uint16_t*>(workspace);
+  float* partial = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) +
+                                            round_up(static_cast<int64_t>(h.xt_bytes), 256));
+  {
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+    DCQ_REQUIRE(aligned || (C % 8) != 0, DCQ_ERR_ARGUMENT, "x must be 16-byte aligned");
+    dim3 grid(static_cast<unsigned>(h.Tp / kTrTile), static_cast<unsigned>(h.Cp / kTrTile));
+    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, s, static_cast<const uint16_t*>(x), T, C, xt, h.Tp);
+    DCQ_LAUNCH_CHECK("transpose_pad_kernel launch");
+  }
+  SyrkParams p{};
+  p.xt = xt;
+  p.Tp = h.Tp;
+  p.C = static_cast<int32_t>(C);
+  p.Cp = static_cast<int32_t>(h.Cp);
+  p.tiles_per_side = h.tiles_side;
+  p.num_tiles = h.num_tiles;
+  p.splits = h.splits;
+  p.ktiles_per_split = h.ktiles_per_split;
+  p.alpha = alpha;
+  p.H = H;
+  p.partial = partial;
+  const size_t lds = 2 * 2 * kOperandBytes;
+  auto kern = storage == DCQ_BF16 ? syrk_kernel<DCQ_BF16> : syrk_kernel<DCQ_F16>;
+  if (lds > 64 * 1024) {
+    int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),
+                       "hipFuncSetAttribute(syrk LDS)");
+    if (rc != DCQ_OK) return rc;
+  }
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(h.num_tiles * h.splits)), dim3(kSyrkThreads), lds, s, p);
+  DCQ_LAUNCH_CHECK("syrk_kernel launch");
+  if (h.splits > 1) {
+    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(static_cast<unsigned>(h.num_tiles)), dim3(256), 0, s, p);
+    DCQ_LAUNCH_CHECK("syrk_reduce_kernel launch");
+  }
+  return DCQ_OK;
+}
+
+int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64_t C, const float* U, int32_t c0,
+                         int32_t bc, const float* scale, const float* zero, float zero_scalar, int32_t row_group_size,
+                         int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
+                         dcq_stream_t stream) {
+  DCQ_REQUIRE(step != nullptr, DCQ_ERR_ARGUMENT, "step is NULL");
+  DCQ_REQUIRE(step->tensor.kind == DCQ_ROUND_INT || step->tensor.kind == DCQ_ROUND_CODEBOOK, DCQ_ERR_UNSUPPORTED,
+              "tensor dtype must be an integer or a codebook type");
+  DCQ_REQUIRE(R >= 0 && C > 0 && ldw >= C, DCQ_ERR_ARGUMENT, "bad sizes");
+  if (R == 0) return DCQ_OK;
+  DCQ_REQUIRE(W && U && scale && perm && Q && Err, DCQ_ERR_ARGUMENT, "NULL buffer");
+  DCQ_REQUIRE(bc >= 1 && bc <= kSweepCols && c0 >= 0 && c0 + bc <= C, DCQ_ERR_ARGUMENT,
+              "bad block [%d, %d) for C=%lld (at most 128 columns per call)", c0, c0 + bc, (long long)C);
+  DCQ_REQUIRE(row_group_size >= 1 && col_group_size >= 1 && col_groups >= 1, DCQ_ERR_ARGUMENT, "bad group geometry");
+  SweepParams p{};
+  p.step = *step;
+  p.W = W;
+  p.ldw = ldw;
+  p.U = U;
+  p.C = C;
+  p.R = R;
+  p.c0 = c0;
+  p.bc = bc;
+  p.scale = scale;
+  p.zero = zero;
+  p.zero_scalar = zero_scalar;
+  p.row_group_size = row_group_size;
+  p.col_group_size = col_group_size;
+  p.col_groups = col_groups;
+  p.perm = perm;
+  p.has_bound_min = step->has_bound_min;
+  p.has_bound_max = step->has_bound_max;
+  p.bound_min = step->bound_min;
+  p.bound_max = step->bound_max;
+  p.Q = Q;
+  p.Err = Err;
+  const size_t lds = kSweepCols * kSweepCols * 4 + 256 * 4;
+  const int rows_per_block = kSweepThreads / kSweepTeam;
+  int64_t blocks = (R + rows_per_block - 1) / rows_per_block;
+  if (blocks > 1024) blocks = 1024;
+  const bool int_q = step->tensor.kind == DCQ_ROUND_INT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define DCQ_SWEEP(ZD)                                                                                       \
+  do {                                                                                                      \
+    auto kern = int_q ? gptq_sweep_kernel<ZD, true> : gptq_sweep_kernel<ZD, false>;                          \
+    int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)), \
+                       "hipFuncSetAttribute(sweep LDS)");                                                    \
+    if (rc != DCQ_OK) return rc;                                                                             \
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kSweepThreads), lds, s, p);           \
+  } while (0)
+  switch (step->zero_domain) {
+    case DCQ_ZERO_NONE:
+      DCQ_SWEEP(DCQ_ZERO_NONE);
+      break;
+    case DCQ_ZERO_PRE_SCALE:
+      DCQ_SWEEP(DCQ_ZERO_PRE_SCALE);
+      break;
+    default:
+      DCQ_SWEEP(DCQ_ZERO_POST_SCALE);
+      break;
+  }
+#undef DCQ_SWEEP
+  DCQ_LAUNCH_CHECK("gptq_sweep_kernel launch");
+  return DCQ_OK;
+}
+
+}  // extern "C"

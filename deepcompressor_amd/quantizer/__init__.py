@@ -1,8 +1,8 @@
 from .config import (BaseKeyEnableQuantKernelConfig, BaseQuantizerConfig, BaseQuantKernel, BaseQuantKernelConfig,
                      DecomposedQuantizerConfig, ProgressiveQuantizerConfig, QuantizerConfig, QuantLowRankConfig)
-from .kernel import QuantRtnKernel
+from .kernel import QuantGptqConfig, QuantGptqKernel, QuantRtnKernel
 from .processor import Quantizer
 
 __all__ = ["Quantizer", "QuantizerConfig", "ProgressiveQuantizerConfig", "DecomposedQuantizerConfig",
            "BaseQuantizerConfig", "BaseQuantKernel", "BaseQuantKernelConfig", "BaseKeyEnableQuantKernelConfig",
-           "QuantLowRankConfig", "QuantRtnKernel"]
+           "QuantLowRankConfig", "QuantRtnKernel", "QuantGptqConfig", "QuantGptqKernel"]

@@ -1,3 +1,4 @@
+from .gptq import QuantGptqConfig, QuantGptqKernel, gptq_quantize
 from .rtn import QuantRtnKernel, rtn_quantize
 
-__all__ = ["QuantRtnKernel", "rtn_quantize"]
+__all__ = ["QuantGptqConfig", "QuantGptqKernel", "gptq_quantize", "QuantRtnKernel", "rtn_quantize"]

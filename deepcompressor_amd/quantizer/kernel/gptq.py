@@ -1,0 +1,186 @@
+"""GPTQ quantization kernel (reference: deepcompressor/quantizer/kernel/gptq.py:23-285).
+
+Same config fields and kernel interface as the reference.  The Hessian X^T X runs on the matrix cores
+(``dcq_hessian_accumulate``), the column sweep of each 128-column block is one HIP kernel with rows as the
+parallel axis (``dcq_gptq_sweep_block``).  Still delegated to library routines through torch in this version:
+the Cholesky factorisations / inverse of the damped Hessian and the float32 lazy-update GEMM between blocks.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from ... import _lib, engine
+from ..._lib import check, lib, ptr, storage_of, stream_of
+from ...data.cache import TensorCache
+from ...data.dtype import QuantDataType
+from ...data.range import QuantRange, RangeBound
+from ...data.zero import ZeroPointDomain
+from ...utils.common import num2str
+from ...utils.config import configclass
+from ..config.kernel import BaseQuantKernel, BaseQuantKernelConfig
+
+__all__ = ["QuantGptqConfig", "QuantGptqKernel", "gptq_quantize", "hessian_accumulate", "cholesky_inverse_upper"]
+
+SWEEP_COLUMNS = 128  # columns per sweep launch; the result does not depend on the block width (only fp order does)
+
+
+@configclass
+@dataclass
+class QuantGptqConfig(BaseQuantKernelConfig):
+    damp_percentage: float = 0.01
+    block_size: int = 128
+    num_inv_tries: int = 200
+    hessian_block_size: int = -1
+
+    @property
+    def name(self) -> str:
+        return "GPTQ"
+
+    def build(self) -> "QuantGptqKernel":
+        return QuantGptqKernel(self)
+
+    def generate_dirnames(self, *, prefix: str = "", **kwargs) -> list[str]:
+        name = f"gptq.d{num2str(self.damp_percentage)}.b{num2str(self.block_size)}"
+        return [f"{prefix}.{name}" if prefix else name]
+
+
+class QuantGptqKernel(BaseQuantKernel):
+    def __init__(self, config: QuantGptqConfig):
+        self.config = config
+
+    def quantize(self, tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: QuantDataType,
+                 zero_domain: ZeroPointDomain | None, scale: torch.Tensor, zero: torch.Tensor, inputs: TensorCache,
+                 quant_range: QuantRange | None = None, range_bound: RangeBound | None = None,
+                 **kwargs) -> torch.Tensor:
+        assert not tensor.requires_grad, "tensor must not require gradient."
+        return gptq_quantize(tensor, view_shape=view_shape, quant_dtype=quant_dtype, zero_domain=zero_domain,
+                             scale=scale, zero=zero, gptq_config=self.config, inputs=inputs, quant_range=quant_range,
+                             range_bound=range_bound)
+
+
+_workspaces: dict[torch.device, torch.Tensor] = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        _workspaces.pop(device, None)
+        ws = None
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def release_workspaces() -> None:
+    _workspaces.clear()
+
+
+def hessian_accumulate(hessian: torch.Tensor, x: torch.Tensor, alpha: float) -> None:
+    """hessian[C][C] += alpha * x^T x for x[N][C] (float16 / bfloat16, on the same GPU)."""
+    assert x.ndim == 2 and hessian.shape == (x.shape[1], x.shape[1]) and hessian.dtype == torch.float32
+    if x.dtype == torch.float32:
+        raise NotImplementedError("float32 calibration activations are not implemented (float16 / bfloat16 are)")
+    x = x.contiguous()
+    T, Cn = x.shape
+    nbytes = lib().dcq_hessian_workspace_bytes(T, Cn)
+    ws = _workspace(x.device, nbytes)
+    check(lib().dcq_hessian_accumulate(ptr(x), storage_of(x.dtype), T, Cn, float(alpha), ptr(hessian), ptr(ws),
+                                       ws.numel(), stream_of(x.device)), "dcq_hessian_accumulate")
+
+
+def cholesky_inverse_upper(hessian: torch.Tensor, diag_mean: torch.Tensor, damp: float, num_tries: int):
+    """U (upper) with U^T U = H^-1; on a failed factorisation adds 0.1 * damp * mean(diag) and retries
+    (gptq.py:215-233).  Returns (U, tries)."""
+    diag = hessian.diagonal()
+    tries, ok, u = 0, False, None
+    while not ok and tries < num_tries:
+        tries += 1
+        try:
+            u = torch.linalg.cholesky(hessian)
+            u = torch.cholesky_inverse(u)
+            u = torch.linalg.cholesky(u, upper=True)
+        except RuntimeError:
+            diag += (damp * 0.1) * diag_mean
+            continue
+        ok = True
+    assert u is not None and not u.isinf().any(), "Inverse of Hessian matrix contains Inf."
+    assert not u.isnan().any(), "Inverse of Hessian matrix contains NaN."
+    return u, tries
+
+
+@torch.no_grad()
+def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: QuantDataType,
+                  zero_domain: ZeroPointDomain | None, scale: torch.Tensor, zero: torch.Tensor,
+                  gptq_config: QuantGptqConfig, inputs: TensorCache, quant_range: QuantRange | None = None,
+                  range_bound: RangeBound | None = None, hessian: torch.Tensor | None = None) -> torch.Tensor:
+    """Quantized values of ``tensor`` (float32 working copy, modified) in the shape ``view_shape``.
+
+    ``hessian`` (optional, not in the reference signature) lets callers that quantize several weights fed by the
+    same activations (q/k/v, gate/up) pass one precomputed 2/n * X^T X instead of recomputing it per weight.
+    """
+    engine._require_gpu(tensor)
+    view = tensor.view(view_shape)
+    view_shape = view.shape
+    if len(view_shape) != 4:
+        raise NotImplementedError("GPTQ is implemented for 2-D weights (linear layers)")
+    n_rg, rg_size, n_cg, cg_size = view_shape
+    R, Cn = n_rg * rg_size, n_cg * cg_size
+    dev = tensor.device
+    W = view.reshape(R, Cn)
+    assert W.dtype == torch.float32, "the working tensor must be float32"
+    # ---- Hessian
+    if hessian is None:
+        hessian = torch.zeros((Cn, Cn), device=dev, dtype=torch.float32)
+        alpha = 2.0 / inputs.num_samples
+        for x in inputs.data:
+            x2 = inputs.reshape(x.view(-1, *x.shape[inputs.channels_dim:]))
+            hessian_accumulate(hessian, x2.to(device=dev, non_blocking=True), alpha)
+    else:
+        hessian = hessian.clone()
+    diag = hessian.diagonal()
+    dead = diag == 0
+    diag[dead] = 1
+    W[:, dead] = 0
+    # ---- act-order permutation, damping, inverse factor
+    perm = torch.argsort(diag, descending=True)
+    hessian = hessian[perm][:, perm]
+    W = W[:, perm].contiguous()
+    inverse_perm = torch.argsort(perm)
+    diag = hessian.diagonal()
+    diag_mean = diag.mean()
+    diag += gptq_config.damp_percentage * diag_mean
+    U, _ = cholesky_inverse_upper(hessian, diag_mean, gptq_config.damp_percentage, gptq_config.num_inv_tries)
+    del hessian
+    # ---- sweep
+    qr = QuantRange.construct(quant_dtype, has_zero_point=zero_domain is not None, quant_range=quant_range)
+    step = engine.make_step(quant_dtype=quant_dtype, zero_domain=zero_domain, tensor_quant_range=qr,
+                            quant_range=quant_range, scale_dtype=torch.float32, zero_dtype=torch.float32,
+                            range_bound=range_bound, q_span=1.0, device=dev)
+    s2 = scale.to(torch.float32).expand(n_rg, 1, n_cg, 1).reshape(n_rg, n_cg).contiguous()
+    zero_is_number = isinstance(zero, (int, float)) or zero.numel() == 1
+    z2, z_scalar = None, 0.0
+    if zero_domain is not None:
+        if zero_is_number:
+            z_scalar = float(zero)
+        else:
+            z2 = zero.to(torch.float32).reshape(n_rg, n_cg).contiguous()
+    Q = torch.zeros_like(W)
+    err = torch.empty((R, SWEEP_COLUMNS), device=dev, dtype=torch.float32)
+    U = U.contiguous()
+    stream = stream_of(dev)
+    for c0 in range(0, Cn, SWEEP_COLUMNS):
+        bc = min(SWEEP_COLUMNS, Cn - c0)
+        check(lib().dcq_gptq_sweep_block(C.byref(step), ptr(W), Cn, R, Cn, ptr(U), c0, bc, ptr(s2), ptr(z2), z_scalar,
+                                         rg_size, cg_size, n_cg, ptr(perm), ptr(Q), ptr(err), stream),
+              "dcq_gptq_sweep_block")
+        c_end = c0 + bc
+        if c_end < Cn:  # lazy update of everything right of the block
+            W[:, c_end:].addmm_(err[:, :bc], U[c0:c_end, c_end:], alpha=-1.0)
+    Q = Q[:, inverse_perm]
+    assert not Q.isnan().any(), "GPTQ Quantized tensor contains NaN."
+    assert not Q.isinf().any(), "GPTQ Quantized tensor contains Inf."
+    return Q.reshape(n_rg, rg_size, n_cg, cg_size).contiguous()

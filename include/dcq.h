@@ -188,6 +188,35 @@ int dcq_range_search_groups(const dcq_step* step, const void* w, int32_t storage
                             float* best_max, float* best_min, float* best_ratio, float* best_error, float* errors,
                             dcq_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * GPTQ (deepcompressor/quantizer/kernel/gptq.py:128-285).
+ *
+ * dcq_hessian_accumulate: H[C][C] += alpha * x^T x for x[T][C] (float16 / bfloat16, row-major), float32
+ * accumulation on the matrix cores; replaces `hessian += matmul(x.t(), x)` with x pre-multiplied by
+ * sqrt(2 / num_samples) (gptq.py:184-194): pass alpha = 2 / num_samples.  Only the upper triangle is
+ * computed and mirrored; the result does not depend on launch timing (no atomics).  `workspace` must hold
+ * dcq_hessian_workspace_bytes(T, C) bytes (256-byte aligned): a zero-padded transpose of x plus split-K
+ * partial tiles.
+ *
+ * dcq_gptq_sweep_block: one block (<= 128 columns, the reference's block_size) of the column loop
+ * (gptq.py:236-268).  W[R][ldw] is the float32 working weight with columns already permuted by `perm`
+ * (act-order) and all previous blocks' lazy updates applied; U[C][C] is the upper Cholesky factor of
+ * H^-1 in permuted order.  For each column c of the block and each row: clamp to the step's RangeBound,
+ * quantize with the scale/zero of original column group perm[c] / col_group_size (gptq.py:246-259),
+ * error = (w - dequant) / U[c][c], and W[:, c+1 : c0+bc] -= error * U[c][c+1 : c0+bc].  Outputs the codes
+ * Q[R][ldw] (permuted column order, block columns only) and Err[R][128] for the caller's lazy update
+ * W[:, c0+bc:] -= Err @ U[c0:c0+bc, c0+bc:] (gptq.py:269).  scale/zero: [R / row_group_size][col_groups].
+ * ------------------------------------------------------------------------------------------- */
+int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C);
+
+int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C, float alpha, float* H, void* workspace,
+                           int64_t workspace_bytes, dcq_stream_t stream);
+
+int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64_t C, const float* U, int32_t c0,
+                         int32_t bc, const float* scale, const float* zero, float zero_scalar, int32_t row_group_size,
+                         int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
+                         dcq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

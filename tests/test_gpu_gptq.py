@@ -1,0 +1,111 @@
+"""GPTQ on the GPU (Hessian on MFMA, HIP column sweep) against the reference fixtures and the CPU oracle.
+
+GPTQ is not bit-reproducible across BLAS / LAPACK implementations; the stated tolerance is: layer output
+max-abs difference <= 1e-3 of the output's max-abs, and >= 99 % identical codes.  The Hessian itself is
+checked against float64.
+"""
+
+import numpy as np
+import pytest
+import torch
+from _product import build_quantizer, to_device, to_np
+from conftest import load_golden
+from test_oracle_gptq import dequant, layer_output_error
+
+import gptq_oracle as go
+import quant_oracle as qo
+from deepcompressor_amd.data.cache import TensorCache
+from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
+from deepcompressor_amd.quantizer import QuantGptqConfig
+from deepcompressor_amd.quantizer.kernel.gptq import hessian_accumulate
+
+pytestmark = pytest.mark.gpu
+GQ = load_golden("gptq")
+FQ = load_golden("fake_quant")
+
+
+@pytest.mark.parametrize("T,C,dt", [(1024, 512, torch.bfloat16), (777, 200, torch.float16), (4096, 384, torch.bfloat16),
+                                    (16384, 1024, torch.float16)])
+def test_hessian_matches_float64(T, C, dt):
+    g = torch.Generator().manual_seed(T + C)
+    x = (torch.randn(T, C, generator=g) * torch.exp(torch.randn(C, generator=g))).to(dt)
+    x[:, 3] = 0
+    H = torch.zeros(C, C, device="cuda")
+    hessian_accumulate(H, x.cuda(), 2.0 / T)
+    hessian_accumulate(H, x.cuda(), 2.0 / T)  # accumulates
+    want = (x.double().T @ x.double()) * (4.0 / T)
+    got = H.cpu().double()
+    assert torch.equal(got, got.T), "Hessian must be exactly symmetric"
+    scale = want.diagonal().sqrt()
+    rel = ((got - want).abs() / (scale[:, None] * scale[None, :] + 1e-30)).max().item()
+    assert rel < 2e-6, rel
+    assert got[3, 3] == 0
+
+
+@pytest.mark.parametrize("tag", sorted(GQ.meta))
+def test_gptq_matches_reference_fixture(tag):
+    m = GQ.meta[tag]
+    case = FQ.meta["cases"][m["case"]]
+    w_np, x_np = GQ[f"{tag}|w"], GQ[f"{tag}|x"]
+    w = to_device(w_np, m["in_dtype"])
+    x = to_device(x_np, m["in_dtype"], device="cpu")  # the calibration cache lives on the host, as in the reference
+    q = build_quantizer(case)
+    cache = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_cached=1, num_total=1,
+                        num_samples=m["num_samples"])
+    kern = QuantGptqConfig(damp_percentage=m["damp"], block_size=m["block"], num_inv_tries=250, hessian_block_size=512)
+    qt = q.quantize(w, kernel=kern, inputs=cache, return_with_dequant=False, return_with_quant=True)
+    dq = q.quantize(w, kernel=kern, inputs=cache)
+    np.testing.assert_array_equal(to_np(qt.scale.data), GQ[f"{tag}|scale"])  # scale/zero: bit-exact (pre-update weights)
+    codes, want = to_np(qt.qdata), GQ[f"{tag}|codes"]
+    same = (codes == want).mean()
+    assert same > 0.99, f"only {same:.4f} of the codes equal the reference's"
+    err = layer_output_error(x_np, to_np(dq.data), GQ[f"{tag}|dequant"])
+    assert err < 1e-3, f"layer output differs from the reference's by {err:.2e}"
+    e_gptq = layer_output_error(x_np, to_np(dq.data), w_np)
+    e_rtn = layer_output_error(x_np, GQ[f"{tag}|rtn_dequant"], w_np)
+    assert e_gptq < e_rtn
+    # the dequantized tensor is exactly the dequantization of the returned codes
+    spec = qo.spec_from_case(case)
+    base = qo.fake_quantize(w_np, m["in_dtype"], spec)
+    again = qo.round_to(m["in_dtype"], dequant(codes, base, spec.steps[0], w_np.shape))
+    np.testing.assert_array_equal(to_np(dq.data), again)
+
+
+def test_gptq_vs_oracle_larger():
+    """768 x 1024 weight, 4096 tokens, ragged last sweep block excluded (C multiple of 128), dead channel included."""
+    case = FQ.meta["cases"]["uint4_post_g128_f16s"]
+    g = torch.Generator().manual_seed(11)
+    w = (torch.randn(768, 1024, generator=g) * 0.02).to(torch.bfloat16)
+    x = (torch.randn(4096, 1024, generator=g) * torch.exp(0.7 * torch.randn(1024, generator=g))).to(torch.bfloat16)
+    x[:, 100] = 0
+    spec = qo.spec_from_case(case)
+    base = qo.fake_quantize(w.float().numpy(), "bf16", spec)
+    want = go.gptq_codes(w.float().numpy(), x.float().numpy(), 4096, spec.steps[0], base["scale"], base["zero"],
+                         base["view_shape"])
+    q = build_quantizer(case)
+    cache = TensorCache([x.view(2, 2048, 1024)], channels_dim=-1, reshape=LinearReshapeFn(), num_samples=4096)
+    qt = q.quantize(w.cuda(), kernel=QuantGptqConfig(hessian_block_size=512), inputs=cache, return_with_dequant=False,
+                    return_with_quant=True)
+    codes = to_np(qt.qdata)
+    assert (codes == want).mean() > 0.99
+    err = layer_output_error(x.float().numpy(), dequant(codes, base, spec.steps[0], w.shape),
+                             dequant(want, base, spec.steps[0], w.shape))
+    assert err < 1e-3, err
+    assert (codes[:, 100] == want[:, 100]).all()
+
+
+def test_gptq_ragged_columns_and_progressive():
+    """C = 320 (last sweep block has 64 columns) and the QoQ two-step config through the GPTQ kernel."""
+    g = torch.Generator().manual_seed(3)
+    for cname, C in (("sint4_g64_defs", 320), ("qoq_g128", 384)):
+        case = FQ.meta["cases"][cname]
+        w = (torch.randn(96, C, generator=g) * 0.03).to(torch.float16)
+        x = (torch.randn(1024, C, generator=g)).to(torch.float16)
+        q = build_quantizer(case)
+        cache = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_samples=1024)
+        dq = q.quantize(w.cuda(), kernel=QuantGptqConfig(), inputs=cache).data
+        rtn = q.quantize(w.cuda()).data
+        xn, wn = x.float().numpy(), w.float().numpy()
+        e_gptq = np.square(xn.astype(np.float64) @ (to_np(dq) - wn).T.astype(np.float64)).sum()
+        e_rtn = np.square(xn.astype(np.float64) @ (to_np(rtn) - wn).T.astype(np.float64)).sum()
+        assert e_gptq < e_rtn, (cname, e_gptq, e_rtn)
