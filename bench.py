@@ -1,0 +1,203 @@
+"""Contract benchmark: quantized params/sec for Llama-3-8B GPTQ W4 g128 + range search (BASELINE.json configs[1]).
+
+One step = the whole weight-quantization hot path for ONE Llama-3-8B decoder layer (7 linears, 218.1 M params)
+against 128 x 2048 = 262,144 synthetic calibration tokens already resident in HBM:
+  per distinct activation (attention input, o_proj input, MLP input, down_proj input): H = 2/n X^T X   (MFMA)
+  per linear: fused 101-candidate range-ratio search -> static ranges -> scales/zeros -> GPTQ sweep -> dequantize.
+Layers are independent, so N GPUs each run K layers (weak scaling, no data-path collective).
+
+    python bench.py [--gpus N --steps K --warmup W] [--tokens T] [--no-cpu-baseline]
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+LLAMA3_8B_LAYER = [  # (name, out_features, in_features, activation id)
+    ("q_proj", 4096, 4096, "attn_in"), ("k_proj", 1024, 4096, "attn_in"), ("v_proj", 1024, 4096, "attn_in"),
+    ("o_proj", 4096, 4096, "attn_out"), ("gate_proj", 14336, 4096, "mlp_in"), ("up_proj", 14336, 4096, "mlp_in"),
+    ("down_proj", 4096, 14336, "mlp_mid"),
+]
+PARAMS_PER_LAYER = sum(r * c for _, r, c, _ in LLAMA3_8B_LAYER)
+
+
+def make_layer(device, tokens: int, seed: int):
+    """Synthetic bf16 weights and activations of one decoder layer (per-channel log-normal activation gains)."""
+    from deepcompressor_amd.data.cache import TensorCache
+    from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    acts, caches = {}, {}
+    for _, _, c, key in LLAMA3_8B_LAYER:
+        if key in acts:
+            continue
+        gains = torch.exp(torch.randn(c, generator=g, device=device))
+        x = torch.empty((tokens, c), dtype=torch.bfloat16, device=device)
+        for t0 in range(0, tokens, 16384):
+            n = min(16384, tokens - t0)
+            x[t0:t0 + n] = (torch.randn((n, c), generator=g, device=device) * gains).to(torch.bfloat16)
+        acts[key] = x
+        caches[key] = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_cached=1, num_total=1,
+                                  num_samples=tokens, orig_device=device)
+    weights = {name: (torch.randn((r, c), generator=g, device=device) * 0.02).to(torch.bfloat16)
+               for name, r, c, _ in LLAMA3_8B_LAYER}
+    return weights, caches
+
+
+def build_objects():
+    from deepcompressor_amd.calib import (DynamicRangeCalibConfig, SearchBasedCalibGranularity,
+                                          SearchBasedCalibObjective, SearchBasedCalibStrategy)
+    from deepcompressor_amd.data.dtype import QDType
+    from deepcompressor_amd.data.zero import ZeroPointDomain
+    from deepcompressor_amd.quantizer import QuantGptqConfig, Quantizer, QuantizerConfig
+
+    # examples/llm/configs/gptq.yaml of the reference with enable_calib_range = true ("GPTQ-R")
+    qcfg = QuantizerConfig(dtype=QDType.uint4, zero_point=ZeroPointDomain.PostScale, group_shapes=((1, 128),),
+                           scale_dtypes=(torch.float16,))
+    rcfg = DynamicRangeCalibConfig(degree=2.4, objective=SearchBasedCalibObjective.TensorError,
+                                   strategy=SearchBasedCalibStrategy.GridSearch,
+                                   granularity=SearchBasedCalibGranularity.Group, max_shrink=0.2, max_expand=1.0,
+                                   num_grids=100)
+    gcfg = QuantGptqConfig(damp_percentage=0.01, block_size=128, num_inv_tries=250, hessian_block_size=512)
+    return Quantizer, qcfg, rcfg, gcfg
+
+
+def quantize_layer(weights, caches, objs, syrk_events=None):
+    """The hot path for one layer; returns the dequantized weights (kept so nothing is optimised away)."""
+    import torch.nn as nn
+
+    from deepcompressor_amd import _lib
+    from deepcompressor_amd.calib import calibrate_dynamic_range
+    from deepcompressor_amd.data.common import TensorType
+    from deepcompressor_amd.quantizer.kernel import gptq as gptq_mod
+
+    Quantizer, qcfg, rcfg, gcfg = objs
+    out = {}
+    for name, _, c, key in LLAMA3_8B_LAYER:
+        w = weights[name]
+        q = Quantizer(qcfg, key=name, kernel=gcfg, develop_dtype=torch.float32)
+        ranges = calibrate_dynamic_range(TensorType.Weights, rcfg, True, q, modules=[None], activations=None,
+                                         weights=[nn.Parameter(w, requires_grad=False)])
+        if syrk_events is not None and gptq_mod._hessian_cache["key"] != gptq_mod._inputs_key(caches[key], w.device):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # torch creates the HIP event lazily on first record; record once so the handles exist
+            e0.record(), e1.record()
+            _lib.lib().dcq_profile_next_hessian(e0.cuda_event, e1.cuda_event)
+            syrk_events.append((e0, e1, c))
+        out[name] = q.quantize(w, dynamic_range=ranges[0], inputs=caches[key]).data
+    gptq_mod.clear_hessian_cache()
+    return out
+
+
+def cpu_baseline(tokens_sample: int = 8192):
+    """The CPU oracle (numpy restatement of the reference) on a bounded sample: k_proj (1024 x 4096) with a
+    reduced token count.  Returns the cpu_baseline object of the bench contract."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+
+    import gptq_oracle as go
+    import quant_oracle as qo
+
+    rng = np.random.default_rng(0)
+    R, C = 1024, 4096
+    w = qo.round_to("bf16", (rng.standard_normal((R, C)) * 0.02).astype(np.float32))
+    x = qo.round_to("bf16", (rng.standard_normal((tokens_sample, C)) * np.exp(rng.standard_normal(C))).astype(np.float32))
+    spec = qo.spec_from_case(dict(dtype="uint4", zero="PostScale", groups=((1, 128),), sdt=("f16",)))
+    t0 = time.perf_counter()
+    best = qo.range_search_group(w, "bf16", spec, qo.range_ratios(100, 0.2, 1.0), 2.4)
+    t_search = time.perf_counter() - t0
+    base = qo.fake_quantize(w, "bf16", spec, dynamic_range=[{"max": best["max"], "min": best["min"]}])
+    t1 = time.perf_counter()
+    go.gptq_codes(w, x, tokens_sample, spec.steps[0], base["scale"], base["zero"], base["view_shape"])
+    t_gptq = time.perf_counter() - t1
+    total = time.perf_counter() - t0
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {
+        "value": R * C / total, "unit": "params/s", "cores": threads, "kind": "port",
+        "sample": (f"k_proj 1024x4096 bf16, range search 101 ratios ({t_search:.1f} s) + GPTQ with {tokens_sample} "
+                   f"calibration tokens instead of 262144 ({t_gptq:.1f} s); numpy oracle, BLAS/LAPACK on {threads} "
+                   "threads, element-wise parts single-threaded"),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tokens", type=int, default=128 * 2048, help="calibration tokens (contract value: 262144)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from deepcompressor_amd.parallel import barrier_and_max
+
+    objs = build_objects()
+    weights, caches = make_layer(device, args.tokens, seed=1234 + rank)
+    for _ in range(args.warmup):
+        quantize_layer(weights, caches, objs)
+    torch.cuda.synchronize()
+    barrier_and_max(0.0, world, device)
+    syrk_events: list = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outputs = quantize_layer(weights, caches, objs, syrk_events)
+    torch.cuda.synchronize()
+    elapsed = barrier_and_max(time.perf_counter() - t0, world, device)
+    del outputs
+
+    if rank == 0:
+        total_params = PARAMS_PER_LAYER * args.steps * world
+        # dominant kernel: the MFMA SYRK.  Algorithmic work of one launch = 2 * T * C^2 flop (X^T X as the reference
+        # computes it); the kernel executes the upper-triangular tiles only.
+        syrk_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in syrk_events)
+        syrk_flop = sum(2.0 * args.tokens * c * c for _, _, c in syrk_events)
+        tiles = lambda c: (-(-c // 128)) * (-(-c // 128) + 1) // 2  # noqa: E731
+        exec_flop = sum(2.0 * args.tokens * tiles(c) * 128 * 128 for _, _, c in syrk_events)
+        achieved = syrk_flop / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+        line = {
+            "metric": "quantized params/sec (whole node), Llama-3-8B GPTQ W4 g128 + range search",
+            "value": total_params / elapsed, "unit": "params/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "GPTQ W4A16 g128 (uint4 PostScale, fp16 scales) + 101-ratio range search on the 7 "
+                                   "linears of one Llama-3-8B decoder layer per step, bf16 weights/activations, "
+                                   f"{args.tokens} calibration tokens resident in HBM",
+                       "params_per_step": PARAMS_PER_LAYER, "tokens": args.tokens,
+                       "parallelism": f"independent layers x{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": achieved / 2500.0, "traffic": None, "kernel": "syrk_kernel (H += 2/n X^T X, bf16 MFMA)",
+                         "launches": len(syrk_events), "avg_launch_ms": syrk_ms / max(1, len(syrk_events)),
+                         "share_of_step": syrk_ms * 1e-3 / elapsed,
+                         "executed_tflops": exec_flop / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,6 +90,8 @@ def lib():
             fn.argtypes, fn.restype = sig, C.c_int
         handle.dcq_hessian_workspace_bytes.argtypes = [_i64, _i64]
         handle.dcq_hessian_workspace_bytes.restype = C.c_int64
+        handle.dcq_profile_next_hessian.argtypes = [_p, _p]
+        handle.dcq_profile_next_hessian.restype = None
         handle.dcq_version.restype = C.c_char_p
         handle.dcq_last_error.restype = C.c_char_p
         _lib = handle

@@ -250,6 +250,8 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkParams p) {
   }
 }
 
+static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+
 static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 struct HessianPlan {
@@ -391,6 +393,11 @@ using namespace dcq;
 
 extern "C" {
 
+void dcq_profile_next_hessian(void* start, void* stop) {
+  g_prof_start = static_cast<hipEvent_t>(start);
+  g_prof_stop = static_cast<hipEvent_t>(stop);
+}
+
 int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C) {
   if (T <= 0 || C <= 0) return 0;
   const HessianPlan h = plan_hessian(T, C);
@@ -442,7 +449,10 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
                        "hipFuncSetAttribute(syrk LDS)");
     if (rc != DCQ_OK) return rc;
   }
+  if (g_prof_start) (void)hipEventRecord(g_prof_start, s);
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(h.num_tiles * h.splits)), dim3(kSyrkThreads), lds, s, p);
+  if (g_prof_stop) (void)hipEventRecord(g_prof_stop, s);
+  g_prof_start = g_prof_stop = nullptr;
   DCQ_LAUNCH_CHECK("syrk_kernel launch");
   if (h.splits > 1) {
     hipLaunchKernelGGL(syrk_reduce_kernel, dim3(static_cast<unsigned>(h.num_tiles)), dim3(256), 0, s, p);

@@ -23,7 +23,8 @@ from ...utils.common import num2str
 from ...utils.config import configclass
 from ..config.kernel import BaseQuantKernel, BaseQuantKernelConfig
 
-__all__ = ["QuantGptqConfig", "QuantGptqKernel", "gptq_quantize", "hessian_accumulate", "cholesky_inverse_upper"]
+__all__ = ["QuantGptqConfig", "QuantGptqKernel", "gptq_quantize", "hessian_accumulate", "hessian_of",
+           "clear_hessian_cache", "cholesky_inverse_upper"]
 
 SWEEP_COLUMNS = 128  # columns per sweep launch; the result does not depend on the block width (only fp order does)
 
@@ -63,6 +64,34 @@ class QuantGptqKernel(BaseQuantKernel):
 
 
 _workspaces: dict[torch.device, torch.Tensor] = {}
+# The weights fed by the same activations (q/k/v, gate/up) share one Hessian: the most recent one is kept,
+# keyed by the identity of the cached activation tensors.
+_hessian_cache: dict = {"key": None, "value": None}
+
+
+def clear_hessian_cache() -> None:
+    _hessian_cache["key"] = _hessian_cache["value"] = None
+
+
+def _inputs_key(inputs: TensorCache, device: torch.device):
+    return (device, inputs.num_samples, inputs.channels_dim,
+            tuple((t.data_ptr(), tuple(t.shape), t.dtype, t._version) for t in inputs.data))
+
+
+def hessian_of(inputs: TensorCache, device: torch.device) -> torch.Tensor:
+    """2 / num_samples * sum_x x^T x over the cache (float32, C x C), memoised for the last cache seen."""
+    key = _inputs_key(inputs, device)
+    if _hessian_cache["key"] != key:
+        _hessian_cache["key"] = _hessian_cache["value"] = None
+        hessian = None
+        alpha = 2.0 / inputs.num_samples
+        for x in inputs.data:
+            x2 = inputs.reshape(x.view(-1, *x.shape[inputs.channels_dim:]))
+            if hessian is None:
+                hessian = torch.zeros((x2.shape[1], x2.shape[1]), device=device, dtype=torch.float32)
+            hessian_accumulate(hessian, x2.to(device=device, non_blocking=True), alpha)
+        _hessian_cache["key"], _hessian_cache["value"] = key, hessian
+    return _hessian_cache["value"]
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
@@ -133,14 +162,8 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     W = view.reshape(R, Cn)
     assert W.dtype == torch.float32, "the working tensor must be float32"
     # ---- Hessian
-    if hessian is None:
-        hessian = torch.zeros((Cn, Cn), device=dev, dtype=torch.float32)
-        alpha = 2.0 / inputs.num_samples
-        for x in inputs.data:
-            x2 = inputs.reshape(x.view(-1, *x.shape[inputs.channels_dim:]))
-            hessian_accumulate(hessian, x2.to(device=dev, non_blocking=True), alpha)
-    else:
-        hessian = hessian.clone()
+    hessian = (hessian_of(inputs, dev) if hessian is None else hessian).clone()
+    assert hessian.shape == (Cn, Cn), "activation channels do not match the weight's input channels"
     diag = hessian.diagonal()
     dead = diag == 0
     diag[dead] = 1

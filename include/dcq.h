@@ -209,6 +209,11 @@ int dcq_range_search_groups(const dcq_step* step, const void* w, int32_t storage
  * ------------------------------------------------------------------------------------------- */
 int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C);
 
+/* Measurement hook (no reference counterpart): the calling thread's next dcq_hessian_accumulate records
+ * `start` right before and `stop` right after its matrix-core kernel on the call's stream (hipEvent_t
+ * handles, created by the caller with timing enabled), then forgets them.  Pass NULLs to disarm. */
+void dcq_profile_next_hessian(void* start, void* stop);
+
 int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C, float alpha, float* H, void* workspace,
                            int64_t workspace_bytes, dcq_stream_t stream);
 
