@@ -64,14 +64,24 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* __re
 }
 
 // =============================================================================================
-// SYRK on MFMA: tile 128 x 128, K step 64, 4 waves (2 x 2), 32x32x16 instructions
+// SYRK on MFMA: tile 128 x 128, K step 64, 4 waves (2 x 2 quadrants of 64 x 64), 32x32x16 instructions.
+//
+// Operand tiles go HBM/L2 -> LDS directly (global_load_lds, 16 B per lane, no VGPR staging).  The LDS image
+// of a tile is row-major [128 rows][8 chunks of 16 B]; one wave-instruction fills 8 consecutive rows, its 8
+// lanes per row fetch one full 128-byte line.  To keep the 16-byte fragment reads conflict-free the chunk
+// position is XOR-swizzled with bits 1..3 of the row; direct-to-LDS writes are lane-linear, so the swizzle is
+// applied to the *global source* chunk and again on the read.
+//
+// Workgroups are renumbered so that the 64 workgroups resident on one XCD (blockIdx = xcd mod 8) cover one
+// 8 x 8 patch of output tiles: every row/column panel streamed from memory is then shared by 8 workgroups
+// through that XCD's L2.
 // =============================================================================================
 constexpr int kTile = 128;
 constexpr int kBK = 64;
-constexpr int kChunks = kBK / 8;                      // 16-byte k-chunks per row
-constexpr int kChunkStride = kTile * 16 + 16;         // bytes: 128 rows x 16 B, +16 so chunk columns shift 4 banks
-constexpr int kOperandBytes = kChunks * kChunkStride;  // one operand tile in LDS
+constexpr int kRowBytes = kBK * 2;                // 128 B per tile row
+constexpr int kOperandBytes = kTile * kRowBytes;  // 16 KiB
 constexpr int kSyrkThreads = 256;
+constexpr int kPatch = 8;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -88,6 +98,11 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(const uint4& a, const uint4& b, 
   }
 }
 
+__device__ __forceinline__ void load_to_lds_16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),
+                                   (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
+}
+
 struct SyrkParams {
   const uint16_t* xt;  // [Cp][Tp]
   int64_t Tp;
@@ -97,64 +112,85 @@ struct SyrkParams {
   int32_t splits;          // K splits
   int32_t ktiles_per_split;
   float alpha;
-  float* H;        // [C][C]
-  float* partial;  // [splits][num_tiles][128*128] when splits > 1
+  float* H;             // [C][C]
+  float* partial;       // [splits][num_tiles][128*128] when splits > 1
+  const int2* tile_map;  // [num_tiles] (bi, bj) in patch-major order
 };
 
-__device__ __forceinline__ void tile_coords(int idx, int n, int& bi, int& bj) {
-  // row-major enumeration of the upper triangle: row bi has n - bi tiles
-  int row = 0, rem = idx;
-  while (rem >= n - row) {
-    rem -= n - row;
-    ++row;
+// tile_map[l] = l-th tile when the upper triangle is walked patch by patch (8 x 8 tiles, patches row-major,
+// tiles inside a patch row-major; diagonal patches keep only bi <= bj)
+__global__ void syrk_tile_map_kernel(int2* map, int n, int num_tiles) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= num_tiles) return;
+  const int P = (n + kPatch - 1) / kPatch;
+  int rem = l;
+  for (int pi = 0; pi < P; ++pi) {
+    const int mi = min(kPatch, n - pi * kPatch);
+    for (int pj = pi; pj < P; ++pj) {
+      const int mj = min(kPatch, n - pj * kPatch);
+      const int count = pi == pj ? mi * (mi + 1) / 2 : mi * mj;
+      if (rem < count) {
+        int i, j;
+        if (pi == pj) {
+          i = 0;
+          while (rem >= mi - i) {
+            rem -= mi - i;
+            ++i;
+          }
+          j = i + rem;
+        } else {
+          i = rem / mj;
+          j = rem % mj;
+        }
+        map[l] = make_int2(pi * kPatch + i, pj * kPatch + j);
+        return;
+      }
+      rem -= count;
+    }
   }
-  bi = row;
-  bj = row + rem;
 }
 
 template <int ST>
 __global__ __launch_bounds__(kSyrkThreads, 2) void syrk_kernel(const SyrkParams p) {
-  extern __shared__ __align__(16) unsigned char lds[];  // [2 buffers][A, B][kOperandBytes]
+  extern __shared__ __align__(1024) unsigned char lds[];  // [2 buffers][A, B][16 KiB]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;  // wave's 64 x 64 quadrant
-  const int tile_idx = blockIdx.x % p.num_tiles;
-  const int split = blockIdx.x / p.num_tiles;
-  int bi, bj;
-  tile_coords(tile_idx, p.tiles_per_side, bi, bj);
+  // XCD-aware renumbering (bijective for any grid size): consecutive logical ids stay on one XCD
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r8 = nwg & 7;
+  const int logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
+  const int split = logical / p.num_tiles;
+  const int tile_idx = logical - split * p.num_tiles;
+  const int2 t = p.tile_map[tile_idx];
+  const int bi = t.x, bj = t.y;
   const bool diag = bi == bj;
 
-  // staging map: thread -> (row, chunk) pieces of a 128 x 64 operand tile; 1024 pieces / 256 threads = 4 each
-  // piece id = it * 256 + tid; row = id / 8, chunk = id % 8  (8 consecutive lanes read one full 128-byte line)
-  const uint16_t* a_base = p.xt + static_cast<int64_t>(bi) * kTile * p.Tp;
-  const uint16_t* b_base = p.xt + static_cast<int64_t>(bj) * kTile * p.Tp;
   const int64_t k_begin = static_cast<int64_t>(split) * p.ktiles_per_split * kBK;
   int64_t k_end = k_begin + static_cast<int64_t>(p.ktiles_per_split) * kBK;
   if (k_end > p.Tp) k_end = p.Tp;
-  const int nk = static_cast<int>((k_end - k_begin) / kBK);
+  const int nk = k_end > k_begin ? static_cast<int>((k_end - k_begin) / kBK) : 0;
 
-  uint4 ra[4], rb[4];
-  auto load_tile = [&](int kt) {
-    const int64_t k0 = k_begin + static_cast<int64_t>(kt) * kBK;
+  // staging: wave w fills rows [32 w, 32 w + 32) of each operand tile with 4 wave-instructions of 8 rows;
+  // lane -> (row = lane / 8, LDS chunk position = lane % 8), global chunk = position ^ ((row >> 1) & 7)
+  const int st_row = lane >> 3, st_pos = lane & 7;
+  const uint16_t* a_src[4];
+  const uint16_t* b_src[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int id = it * kSyrkThreads + tid;
-      const int row = id >> 3, chunk = id & 7;
-      ra[it] = *reinterpret_cast<const uint4*>(a_base + static_cast<int64_t>(row) * p.Tp + k0 + chunk * 8);
-      if (!diag) rb[it] = *reinterpret_cast<const uint4*>(b_base + static_cast<int64_t>(row) * p.Tp + k0 + chunk * 8);
-    }
-  };
-  auto store_tile = [&](int buf) {
-    unsigned char* a_lds = lds + buf * 2 * kOperandBytes;
-    unsigned char* b_lds = a_lds + kOperandBytes;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int id = it * kSyrkThreads + tid;
-      const int row = id >> 3, chunk = id & 7;
-      *reinterpret_cast<uint4*>(a_lds + chunk * kChunkStride + row * 16) = ra[it];
-      if (!diag) *reinterpret_cast<uint4*>(b_lds + chunk * kChunkStride + row * 16) = rb[it];
-    }
-  };
+  for (int it = 0; it < 4; ++it) {
+    const int row = wave * 32 + it * 8 + st_row;
+    const int chunk = st_pos ^ ((row >> 1) & 7);
+    a_src[it] = p.xt + (static_cast<int64_t>(bi) * kTile + row) * p.Tp + k_begin + chunk * 8;
+    b_src[it] = p.xt + (static_cast<int64_t>(bj) * kTile + row) * p.Tp + k_begin + chunk * 8;
+  }
+#define DCQ_STAGE(buf, kt)                                                                      \
+  do {                                                                                          \
+    unsigned char* a_dst = lds + (buf) * 2 * kOperandBytes + wave * 32 * kRowBytes;             \
+    unsigned char* b_dst = a_dst + kOperandBytes;                                               \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                          \
+      load_to_lds_16(a_src[it] + static_cast<int64_t>(kt) * kBK, a_dst + it * 8 * kRowBytes);   \
+      if (!diag) load_to_lds_16(b_src[it] + static_cast<int64_t>(kt) * kBK, b_dst + it * 8 * kRowBytes); \
+    }                                                                                           \
+  } while (0)
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -164,15 +200,22 @@ __global__ __launch_bounds__(kSyrkThreads, 2) void syrk_kernel(const SyrkParams 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
-  if (nk > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
+  if (nk > 0) DCQ_STAGE(0, 0);
   __syncthreads();
+  // fragment addressing: lane -> tile row (lane & 31), k-chunk (2 ks + (lane >> 5)), swizzled position
   const int frag_row = lane & 31, frag_half = lane >> 5;
+  int a_off[2], b_off[2], a_sw[2], b_sw[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int ra = wr * 64 + m * 32 + frag_row, rb = wc * 64 + m * 32 + frag_row;
+    a_off[m] = ra * kRowBytes;
+    a_sw[m] = (ra >> 1) & 7;
+    b_off[m] = rb * kRowBytes;
+    b_sw[m] = (rb >> 1) & 7;
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < nk) DCQ_STAGE(buf ^ 1, kt + 1);
     const unsigned char* a_lds = lds + buf * 2 * kOperandBytes;
     const unsigned char* b_lds = diag ? a_lds : a_lds + kOperandBytes;
 #pragma unroll
@@ -180,19 +223,17 @@ __global__ __launch_bounds__(kSyrkThreads, 2) void syrk_kernel(const SyrkParams 
       const int chunk = ks * 2 + frag_half;
       uint4 af[2], bf[2];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-        af[m] = *reinterpret_cast<const uint4*>(a_lds + chunk * kChunkStride + (wr * 64 + m * 32 + frag_row) * 16);
+      for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const uint4*>(a_lds + a_off[m] + ((chunk ^ a_sw[m]) << 4));
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-        bf[n] = *reinterpret_cast<const uint4*>(b_lds + chunk * kChunkStride + (wc * 64 + n * 32 + frag_row) * 16);
+      for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const uint4*>(b_lds + b_off[n] + ((chunk ^ b_sw[n]) << 4));
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = mfma_32x32x16<ST>(af[m], bf[n], acc[m][n]);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
-    __syncthreads();
+    __syncthreads();  // drains the direct-to-LDS loads of tile kt + 1 and fences the reads of tile kt
   }
+#undef DCQ_STAGE
 
   // epilogue.  C/D layout of the 32x32 instruction: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int col_in = lane & 31, row_off = 4 * (lane >> 5);
@@ -233,8 +274,8 @@ __global__ __launch_bounds__(kSyrkThreads, 2) void syrk_kernel(const SyrkParams 
 // H[tile] += alpha * sum_s partial[s][tile]  (fixed order), mirrored
 __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkParams p) {
   const int tile_idx = blockIdx.x;
-  int bi, bj;
-  tile_coords(tile_idx, p.tiles_per_side, bi, bj);
+  const int2 t = p.tile_map[tile_idx];
+  const int bi = t.x, bj = t.y;
   for (int e = threadIdx.x; e < kTile * kTile; e += 256) {
     const int r = e / kTile, c = e % kTile;
     const int row = bi * kTile + r, col = bj * kTile + c;
@@ -257,7 +298,7 @@ static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 struct HessianPlan {
   int64_t Cp, Tp;
   int tiles_side, num_tiles, splits, ktiles_per_split;
-  size_t xt_bytes, partial_bytes;
+  size_t xt_bytes, map_bytes, partial_bytes;
 };
 
 static HessianPlan plan_hessian(int64_t T, int64_t C) {
@@ -272,7 +313,8 @@ static HessianPlan plan_hessian(int64_t T, int64_t C) {
   while (static_cast<int64_t>(h.num_tiles) * splits < 2048 && ktiles / (splits * 2) >= 32 && splits < 64) splits *= 2;
   h.splits = splits;
   h.ktiles_per_split = (ktiles + splits - 1) / splits;
-  h.xt_bytes = static_cast<size_t>(h.Cp) * h.Tp * 2;
+  h.xt_bytes = static_cast<size_t>(round_up(h.Cp * h.Tp * 2, 256));
+  h.map_bytes = static_cast<size_t>(round_up(static_cast<int64_t>(h.num_tiles) * 8, 256));
   h.partial_bytes = splits > 1 ? static_cast<size_t>(splits) * h.num_tiles * kTile * kTile * 4 : 0;
   return h;
 }
@@ -401,7 +443,7 @@ void dcq_profile_next_hessian(void* start, void* stop) {
 int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C) {
   if (T <= 0 || C <= 0) return 0;
   const HessianPlan h = plan_hessian(T, C);
-  return static_cast<int64_t>(round_up(static_cast<int64_t>(h.xt_bytes), 256) + h.partial_bytes);
+  return static_cast<int64_t>(h.xt_bytes + h.map_bytes + h.partial_bytes);
 }
 
 int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C, float alpha, float* H, void* workspace,
@@ -420,8 +462,8 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
               (long long)dcq_hessian_workspace_bytes(T, C));
   hipStream_t s = static_cast<hipStream_t>(stream);
   uint16_t* xt = static_cast<uint16_t*>(workspace);
-  float* partial = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) +
-                                            round_up(static_cast<int64_t>(h.xt_bytes), 256));
+  int2* tile_map = reinterpret_cast<int2*>(static_cast<unsigned char*>(workspace) + h.xt_bytes);
+  float* partial = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + h.xt_bytes + h.map_bytes);
   {
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
     DCQ_REQUIRE(aligned || (C % 8) != 0, DCQ_ERR_ARGUMENT, "x must be 16-byte aligned");
@@ -429,7 +471,11 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
     hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, s, static_cast<const uint16_t*>(x), T, C, xt, h.Tp);
     DCQ_LAUNCH_CHECK("transpose_pad_kernel launch");
   }
+  hipLaunchKernelGGL(syrk_tile_map_kernel, dim3((h.num_tiles + 255) / 256), dim3(256), 0, s, tile_map, h.tiles_side,
+                     h.num_tiles);
+  DCQ_LAUNCH_CHECK("syrk_tile_map_kernel launch");
   SyrkParams p{};
+  p.tile_map = tile_map;
   p.xt = xt;
   p.Tp = h.Tp;
   p.C = static_cast<int32_t>(C);

@@ -123,20 +123,31 @@ def hessian_accumulate(hessian: torch.Tensor, x: torch.Tensor, alpha: float) -> 
 
 def cholesky_inverse_upper(hessian: torch.Tensor, diag_mean: torch.Tensor, damp: float, num_tries: int):
     """U (upper) with U^T U = H^-1; on a failed factorisation adds 0.1 * damp * mean(diag) and retries
-    (gptq.py:215-233).  Returns (U, tries)."""
+    (gptq.py:215-233).  Returns (U, tries).
+
+    The reference factors H = L L^T, forms H^-1 from L and factors that again.  The same U comes out of ONE
+    factorisation: with J the index reversal, J H J = M M^T (M lower) gives H = V V^T with V = J M J upper
+    triangular, hence H^-1 = (V^-1)^T (V^-1) and, by uniqueness of the Cholesky factor, U = V^-1 -- a
+    triangular inverse instead of a symmetric inverse plus a second factorisation (half the flops, and no
+    second loss of accuracy).
+    """
     diag = hessian.diagonal()
-    tries, ok, u = 0, False, None
-    while not ok and tries < num_tries:
+    n = hessian.shape[0]
+    tries, u = 0, None
+    eye = None
+    while u is None and tries < num_tries:
         tries += 1
-        try:
-            u = torch.linalg.cholesky(hessian)
-            u = torch.cholesky_inverse(u)
-            u = torch.linalg.cholesky(u, upper=True)
-        except RuntimeError:
+        m, info = torch.linalg.cholesky_ex(hessian.flip(0, 1))
+        if int(info) != 0:
             diag += (damp * 0.1) * diag_mean
             continue
-        ok = True
-    assert u is not None and not u.isinf().any(), "Inverse of Hessian matrix contains Inf."
+        v = m.flip(0, 1)
+        del m
+        if eye is None:
+            eye = torch.eye(n, device=hessian.device, dtype=hessian.dtype)
+        u = torch.linalg.solve_triangular(v, eye, upper=True)
+    assert u is not None, "Hessian could not be factorised"
+    assert not u.isinf().any(), "Inverse of Hessian matrix contains Inf."
     assert not u.isnan().any(), "Inverse of Hessian matrix contains NaN."
     return u, tries
 
