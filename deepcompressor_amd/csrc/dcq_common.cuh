@@ -21,6 +21,11 @@ constexpr int kWave = 64;
 void set_error(const char* fmt, ...);
 int hip_check(hipError_t e, const char* what);
 
+// lean fused kernel (dcq_fused.hip); DCQ_ERR_UNSUPPORTED means "use the general kernel"
+int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t G, int64_t S, const float* range_max,
+                         const float* range_min, int has_ratio, float ratio, void* dequant, float* codes, float* scale,
+                         float* zero, hipStream_t stream);
+
 #define DCQ_REQUIRE(cond, code, ...) \
   do {                               \
     if (!(cond)) {                   \

@@ -7,6 +7,7 @@
 // re-read from L2 for the second pass).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "dcq_common.cuh"
 
@@ -506,6 +507,11 @@ int dcq_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, 
               "a static range with a zero point needs range_min");
   DCQ_REQUIRE(!(range_max && has_ratio), DCQ_ERR_UNSUPPORTED,
               "ratio together with a bounding range: use dcq_group_range + dcq_range_to_scale");
+  if (getenv("DCQ_NO_LEAN_KERNEL") == nullptr) {
+    rc = try_launch_fused_int(*step, x, storage, G, S, range_max, range_min, has_ratio, ratio, dequant, codes, scale,
+                              zero, static_cast<hipStream_t>(stream));
+    if (rc != DCQ_ERR_UNSUPPORTED) return rc;
+  }
   GroupParams p{};
   p.step = *step;
   p.x = x;

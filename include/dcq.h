@@ -188,6 +188,12 @@ int dcq_range_search_groups(const dcq_step* step, const void* w, int32_t storage
                             float* best_max, float* best_min, float* best_ratio, float* best_error, float* errors,
                             dcq_stream_t stream);
 
+/* Self-test hook (no reference counterpart): evaluates the kernels' division-by-group-scale routine
+ * (fast[i]; used_fast[i] says whether the reciprocal path or the plain division was taken) next to the
+ * hardware's IEEE division (ref[i]) for n pairs (x[i], s[i]), so a test can assert bitwise equality. */
+int dcq_selftest_division(const float* x, const float* s, float* fast, float* ref, int32_t* used_fast, int64_t n,
+                          dcq_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GPTQ (deepcompressor/quantizer/kernel/gptq.py:128-285).
  *

@@ -104,3 +104,36 @@ def test_codebook_round_matches_oracle():
         x = torch.cat([x, mids, torch.from_numpy(cb)])
         got = d.get_codebook(device="cuda").round(x.cuda())
         assert_bit_equal(to_np(got), qo.codebook_round(x.numpy(), cb), name)
+
+
+def test_division_by_group_scale_is_ieee_exact():
+    """The reciprocal-based division used inside the fused kernel equals the hardware IEEE division bit for bit."""
+    import ctypes as C
+
+    from deepcompressor_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    n = 1 << 24
+    # scales like real ones (fp16-rounded positives over many binades) and all kinds of numerators
+    s = torch.exp2(torch.rand(n, generator=g) * 40 - 30).to(torch.float16).float().clamp_min(2.0 ** -24)
+    x = torch.randn(n, generator=g) * torch.exp2(torch.randint(-20, 8, (n,), generator=g).float())
+    # numerators that land exactly on / next to rounding boundaries k + 0.5
+    k = torch.randint(-128, 128, (n // 4,), generator=g).float() + 0.5
+    x[: n // 4] = k * s[: n // 4]
+    x[n // 4: n // 2] = torch.nextafter(k * s[n // 4: n // 2], torch.full((n // 4,), 1e30))
+    # bf16 numerators, subnormals, zeros, huge values
+    x[n // 2: 3 * n // 4] = x[n // 2: 3 * n // 4].to(torch.bfloat16).float()
+    x[-1000:] = 0
+    x[-2000:-1000] = 1e-41
+    x[-3000:-2000] = 3e38
+    s[-4000:-3000] = 2.0 ** -70
+    xd, sd = x.cuda(), s.cuda()
+    fast, ref = torch.empty_like(xd), torch.empty_like(xd)
+    used = torch.empty(n, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().dcq_selftest_division(_lib.ptr(xd), _lib.ptr(sd), _lib.ptr(fast), _lib.ptr(ref),
+                                                _lib.ptr(used), n, _lib.stream_of(xd.device)), "selftest")
+    same = (fast.view(torch.int32) == ref.view(torch.int32))
+    tiny = (xd.abs() < 2.0 ** -96) & (used == 1)  # documented exemption: |x/s| < 2^-36, rounding-irrelevant
+    assert bool((same | tiny).all()), f"{int((~(same | tiny)).sum())} quotients differ from IEEE division"
+    assert bool(((fast - ref).abs()[tiny] <= ref.abs()[tiny] * 1e-6 + 1e-44).all())
+    assert int(used.sum()) > n * 0.9
+    assert torch.equal(ref.cpu(), x / s)
