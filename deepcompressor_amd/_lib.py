@@ -71,6 +71,8 @@ _SIGNATURES = {
     "dcq_hessian_accumulate": [_p, _i32, _i64, _i64, _f, _p, _p, _i64, _p],
     "dcq_gptq_sweep_block": [C.POINTER(Step), _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _f, _i32, _i32, _i32, _p,
                              _p, _p, _p],
+    "dcq_gemm_f32": [_p, _i64, _i32, _p, _i64, _p, _i64, _i64, _i64, _i64, _f, _f, _p],
+    "dcq_cholesky_inverse_upper": [_p, _i64, _p, _f, _p, _p, _i64, _p, _p],
     "dcq_range_search_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _i32, _d, _p, _p, _p, _p, _p, _p, _p],
 }
 _lib = None
@@ -91,6 +93,8 @@ def lib():
             fn.argtypes, fn.restype = sig, C.c_int
         handle.dcq_hessian_workspace_bytes.argtypes = [_i64, _i64]
         handle.dcq_hessian_workspace_bytes.restype = C.c_int64
+        handle.dcq_cholesky_workspace_bytes.argtypes = [_i64]
+        handle.dcq_cholesky_workspace_bytes.restype = C.c_int64
         handle.dcq_profile_next_hessian.argtypes = [_p, _p]
         handle.dcq_profile_next_hessian.restype = None
         handle.dcq_version.restype = C.c_char_p

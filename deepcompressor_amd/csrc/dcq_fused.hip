@@ -9,6 +9,8 @@
 //   * min/max over the team by xor butterflies, scale / zero computed redundantly in registers.
 //
 // Arithmetic is the reference's, operation by operation (IEEE division, round-half-even, no FMA contraction).
+#include <stdlib.h>
+
 #include "dcq_common.cuh"
 
 namespace dcq {
@@ -305,7 +307,11 @@ template <int ST, int ZD, int SK>
 static int launch_fused(const FusedParams& p, hipStream_t stream) {
   const int64_t threads = p.G * p.team_lanes;
   int64_t blocks = (threads + 255) / 256;
-  const int64_t cap = 256 * 32;
+  if (p.chunks == 1) blocks = (blocks + 1) / 2;  // two groups per team and pass
+  // measured on MI355X: tensors up to a few hundred MB run best on a small persistent grid (2048 workgroups,
+  // each team looping over several groups); beyond the Infinity Cache an un-looped grid is ~12 % faster
+  const char* cap_env = getenv("DCQ_FUSED_GRID_CAP");
+  const int64_t cap = cap_env ? atoll(cap_env) : (blocks > 32768 ? blocks : 2048);
   if (blocks > cap) blocks = cap;
   if (p.chunks == 1) {
     hipLaunchKernelGGL((fused_int_kernel<ST, ZD, SK, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,

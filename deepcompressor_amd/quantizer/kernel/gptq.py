@@ -2,8 +2,9 @@
 
 Same config fields and kernel interface as the reference.  The Hessian X^T X runs on the matrix cores
 (``dcq_hessian_accumulate``), the column sweep of each 128-column block is one HIP kernel with rows as the
-parallel axis (``dcq_gptq_sweep_block``).  Still delegated to library routines through torch in this version:
-the Cholesky factorisations / inverse of the damped Hessian and the float32 lazy-update GEMM between blocks.
+parallel axis (``dcq_gptq_sweep_block``), the inverse Cholesky factor of the damped Hessian is a blocked
+factorisation + triangular inverse on the float32 matrix-core GEMM (``dcq_cholesky_inverse_upper``), and the
+lazy update between blocks is that same GEMM (``dcq_gemm_f32``).
 """
 
 from __future__ import annotations
@@ -24,7 +25,7 @@ from ...utils.config import configclass
 from ..config.kernel import BaseQuantKernel, BaseQuantKernelConfig
 
 __all__ = ["QuantGptqConfig", "QuantGptqKernel", "gptq_quantize", "hessian_accumulate", "hessian_of",
-           "clear_hessian_cache", "cholesky_inverse_upper"]
+           "clear_hessian_cache", "cholesky_inverse_upper", "gemm_f32"]
 
 SWEEP_COLUMNS = 128  # columns per sweep launch; the result does not depend on the block width (only fp order does)
 
@@ -121,32 +122,50 @@ def hessian_accumulate(hessian: torch.Tensor, x: torch.Tensor, alpha: float) -> 
                                        ws.numel(), stream_of(x.device)), "dcq_hessian_accumulate")
 
 
-def cholesky_inverse_upper(hessian: torch.Tensor, diag_mean: torch.Tensor, damp: float, num_tries: int):
-    """U (upper) with U^T U = H^-1; on a failed factorisation adds 0.1 * damp * mean(diag) and retries
-    (gptq.py:215-233).  Returns (U, tries).
+def gemm_f32(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0,
+             a_transposed: bool = False) -> None:
+    """c = beta * c + alpha * a @ b on the float32 matrix-core path (``a`` holds a^T when ``a_transposed``).
+    Operands are 2-D float32 views with unit stride along their last dimension."""
+    for t in (a, b, c):
+        assert t.dtype == torch.float32 and t.ndim == 2 and t.stride(1) == 1, "float32 row-major views expected"
+    K, N = b.shape
+    M = a.shape[1] if a_transposed else a.shape[0]
+    assert (a.shape[0] if a_transposed else a.shape[1]) == K and c.shape == (M, N), "shape mismatch"
+    if M == 0 or N == 0:
+        return
+    raw = lambda t: C.c_void_p(t.data_ptr())  # strided views: the leading dimensions carry the layout
+    engine._require_gpu(c)
+    check(lib().dcq_gemm_f32(raw(a), a.stride(0), int(a_transposed), raw(b), b.stride(0), raw(c), c.stride(0), M, N, K,
+                             float(alpha), float(beta), stream_of(c.device)), "dcq_gemm_f32")
 
-    The reference factors H = L L^T, forms H^-1 from L and factors that again.  The same U comes out of ONE
-    factorisation: with J the index reversal, J H J = M M^T (M lower) gives H = V V^T with V = J M J upper
-    triangular, hence H^-1 = (V^-1)^T (V^-1) and, by uniqueness of the Cholesky factor, U = V^-1 -- a
+
+def cholesky_inverse_upper(hessian: torch.Tensor, perm: torch.Tensor | None, diag_mean: float, damp: float,
+                           num_tries: int):
+    """U (upper) with U^T U = S^-1 for S = P H' P^T + damping, H' = ``hessian`` with dead (zero) diagonal
+    entries set to 1, P the act-order gather ``perm``.  Damping starts at ``damp * diag_mean`` and grows by a tenth
+    of that on each failed factorisation (gptq.py:209-233).  Returns (U, tries); ``hessian`` is left untouched.
+
+    The reference factors S = L L^T, forms S^-1 from L and factors that again.  The same U comes out of ONE
+    factorisation: with J the index reversal, J S J = R^T R (R upper) gives S = V V^T with V = J R^T J upper
+    triangular, hence S^-1 = (V^-1)^T (V^-1) and, by uniqueness of the Cholesky factor, U = V^-1 -- a
     triangular inverse instead of a symmetric inverse plus a second factorisation (half the flops, and no
-    second loss of accuracy).
+    second loss of accuracy).  Both steps run in ``dcq_cholesky_inverse_upper``.
     """
-    diag = hessian.diagonal()
     n = hessian.shape[0]
-    tries, u = 0, None
-    eye = None
-    while u is None and tries < num_tries:
+    assert hessian.shape == (n, n) and hessian.dtype == torch.float32 and hessian.is_contiguous()
+    dev = hessian.device
+    u = torch.empty((n, n), device=dev, dtype=torch.float32)
+    info = torch.empty(1, device=dev, dtype=torch.int32)
+    nbytes = lib().dcq_cholesky_workspace_bytes(n)
+    ws = _workspace(dev, nbytes)
+    tries, done = 0, False
+    while not done and tries < num_tries:
+        diag_add = damp * diag_mean * (1.0 + 0.1 * tries)
         tries += 1
-        m, info = torch.linalg.cholesky_ex(hessian.flip(0, 1))
-        if int(info) != 0:
-            diag += (damp * 0.1) * diag_mean
-            continue
-        v = m.flip(0, 1)
-        del m
-        if eye is None:
-            eye = torch.eye(n, device=hessian.device, dtype=hessian.dtype)
-        u = torch.linalg.solve_triangular(v, eye, upper=True)
-    assert u is not None, "Hessian could not be factorised"
+        check(lib().dcq_cholesky_inverse_upper(ptr(hessian), n, ptr(perm), float(diag_add), ptr(u), ptr(ws), ws.numel(),
+                                               ptr(info), stream_of(dev)), "dcq_cholesky_inverse_upper")
+        done = int(info.item()) == 0
+    assert done, "Hessian could not be factorised"
     assert not u.isinf().any(), "Inverse of Hessian matrix contains Inf."
     assert not u.isnan().any(), "Inverse of Hessian matrix contains NaN."
     return u, tries
@@ -172,23 +191,17 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     dev = tensor.device
     W = view.reshape(R, Cn)
     assert W.dtype == torch.float32, "the working tensor must be float32"
-    # ---- Hessian
-    hessian = (hessian_of(inputs, dev) if hessian is None else hessian).clone()
+    # ---- Hessian (shared, never modified), dead channels, act-order permutation, damping, inverse factor
+    hessian = hessian_of(inputs, dev) if hessian is None else hessian
     assert hessian.shape == (Cn, Cn), "activation channels do not match the weight's input channels"
     diag = hessian.diagonal()
     dead = diag == 0
-    diag[dead] = 1
-    W[:, dead] = 0
-    # ---- act-order permutation, damping, inverse factor
+    diag = torch.where(dead, torch.ones_like(diag), diag)
     perm = torch.argsort(diag, descending=True)
-    hessian = hessian[perm][:, perm]
-    W = W[:, perm].contiguous()
+    W = torch.where(dead, torch.zeros((), device=dev, dtype=W.dtype), W)[:, perm].contiguous()
     inverse_perm = torch.argsort(perm)
-    diag = hessian.diagonal()
-    diag_mean = diag.mean()
-    diag += gptq_config.damp_percentage * diag_mean
-    U, _ = cholesky_inverse_upper(hessian, diag_mean, gptq_config.damp_percentage, gptq_config.num_inv_tries)
-    del hessian
+    diag_mean = float(diag.mean())
+    U, _ = cholesky_inverse_upper(hessian, perm, diag_mean, gptq_config.damp_percentage, gptq_config.num_inv_tries)
     # ---- sweep
     qr = QuantRange.construct(quant_dtype, has_zero_point=zero_domain is not None, quant_range=quant_range)
     step = engine.make_step(quant_dtype=quant_dtype, zero_domain=zero_domain, tensor_quant_range=qr,
@@ -213,7 +226,7 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
               "dcq_gptq_sweep_block")
         c_end = c0 + bc
         if c_end < Cn:  # lazy update of everything right of the block
-            W[:, c_end:].addmm_(err[:, :bc], U[c0:c_end, c_end:], alpha=-1.0)
+            gemm_f32(err, U[c0:c_end, c_end:], W[:, c_end:], alpha=-1.0, beta=1.0)
     Q = Q[:, inverse_perm]
     assert not Q.isnan().any(), "GPTQ Quantized tensor contains NaN."
     assert not Q.isinf().any(), "GPTQ Quantized tensor contains Inf."

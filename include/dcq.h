@@ -228,6 +228,31 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
                          int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
                          dcq_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense float32 linear algebra of GPTQ on the matrix cores.
+ *
+ * dcq_gemm_f32: C[M][N] = beta * C + alpha * A * B with B row-major [K][N] (ldb) and A either row-major
+ * [M][K] (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1), leading dimension lda.  K must be a
+ * multiple of 32; A, B 16-byte aligned with lda, ldb multiples of 4.  Replaces the lazy update
+ * `W[:, c_end:] -= Err @ U[c0:c_end, c_end:]` (gptq.py:269) and is the building block of the routine below.
+ *
+ * dcq_cholesky_inverse_upper: U[n][n] (upper triangular, row-major) with U^T U = S^-1 where
+ *     S = P H' P^T + diag_add * I,   H' = H with zero diagonal entries set to 1 (gptq.py:199-201),
+ *     P = row/column gather by perm[n] (act-order, gptq.py:204-208; NULL = identity).
+ * Replaces `cholesky -> cholesky_inverse -> cholesky(upper=True)` (gptq.py:215-233) by one blocked
+ * factorisation of the index-reversed matrix plus a blocked triangular inverse, which yields the same
+ * factor.  H is not modified.  *info (device int32) receives 0, or the 1-based index (in the reversed
+ * order) of the first non-positive pivot -- the caller then raises diag_add and retries, as the
+ * reference does on torch's LinAlgError.  `workspace`: dcq_cholesky_workspace_bytes(n) bytes, 256-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int dcq_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
+                 int64_t M, int64_t N, int64_t K, float alpha, float beta, dcq_stream_t stream);
+
+int64_t dcq_cholesky_workspace_bytes(int64_t n);
+
+int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U, void* workspace,
+                               int64_t workspace_bytes, int32_t* info, dcq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ import quant_oracle as qo
 from deepcompressor_amd.data.cache import TensorCache
 from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
 from deepcompressor_amd.quantizer import QuantGptqConfig
-from deepcompressor_amd.quantizer.kernel.gptq import hessian_accumulate
+from deepcompressor_amd.quantizer.kernel.gptq import cholesky_inverse_upper, gemm_f32, hessian_accumulate
 
 pytestmark = pytest.mark.gpu
 GQ = load_golden("gptq")
@@ -40,6 +40,73 @@ def test_hessian_matches_float64(T, C, dt):
     rel = ((got - want).abs() / (scale[:, None] * scale[None, :] + 1e-30)).max().item()
     assert rel < 2e-6, rel
     assert got[3, 3] == 0
+
+
+@pytest.mark.parametrize("M,N,K,a_t", [(128, 128, 32, False), (96, 200, 128, False), (300, 515, 64, True),
+                                       (1024, 2048, 128, False), (257, 129, 256, True), (4, 4, 32, False)])
+def test_gemm_f32_matches_float64(M, N, K, a_t):
+    """c = beta c + alpha a b on the float32 matrix-core path: ragged M / N edges, both A layouts, strided views."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g)
+    b_full = torch.randn(K, N + 12, generator=g)
+    c_full = torch.randn(M, N + 8, generator=g)
+    b, c = b_full[:, 12:], c_full[:, 8:]  # column offsets keep 16-byte alignment but make the views strided
+    want = 0.5 * c.double() - 1.25 * (a.double() @ b.double())
+    a_dev = (a.T.contiguous() if a_t else a).cuda()
+    b_dev, c_dev = b_full.cuda(), c_full.cuda()
+    gemm_f32(a_dev, b_dev[:, 12:], c_dev[:, 8:], alpha=-1.25, beta=0.5, a_transposed=a_t)
+    got = c_dev.cpu()
+    assert torch.equal(got[:, :8], c_full[:, :8]), "columns outside the view must stay untouched"
+    err = (got[:, 8:].double() - want).abs().max().item()
+    assert err < 2e-5 * (K ** 0.5), err
+
+
+@pytest.mark.parametrize("n,use_perm", [(128, False), (200, True), (640, True), (1000, False), (2048, True)])
+def test_inverse_factor_matches_float64(n, use_perm):
+    """U from the blocked factorisation + triangular inverse vs the reference route
+    (cholesky -> cholesky_inverse -> cholesky(upper), gptq.py:215-233) evaluated in float64."""
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(4 * n, n, generator=g) * torch.exp(0.5 * torch.randn(n, generator=g))
+    x[:, 5] = 0  # dead channel: zero row / column, diagonal treated as 1
+    h = (x.T @ x) * (2.0 / x.shape[0])
+    diag = torch.where(h.diagonal() == 0, torch.ones(n), h.diagonal())
+    perm = torch.argsort(diag, descending=True) if use_perm else None
+    mean = float(diag.mean())
+    u, tries = cholesky_inverse_upper(h.cuda(), None if perm is None else perm.cuda(), mean, 0.01, 10)
+    assert tries == 1
+    s = h.double().clone()
+    s.diagonal().copy_(diag.double())
+    if perm is not None:
+        s = s[perm][:, perm]
+    s.diagonal().add_(0.01 * mean)
+    want = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(s)), upper=True)
+    got = u.cpu().double()
+    assert torch.equal(got, got.triu()), "U must be upper triangular"
+    rel = ((got - want).abs().max() / want.abs().max()).item()
+    assert rel < 2e-4, rel
+    resid = (got.T @ got @ s - torch.eye(n, dtype=torch.double)).abs().max().item()
+    assert resid < 5e-3, resid
+
+
+def test_inverse_factor_retries_with_more_damping():
+    """A matrix that is not positive definite at the first damping level succeeds after retries (gptq.py:221-230)."""
+    n = 256
+    g = torch.Generator().manual_seed(1)
+    q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.double))
+    eig = torch.linspace(1.0, 2.0, n, dtype=torch.double)
+    eig[0] = -0.0135  # needs damping > 0.0135: with mean(diag) ~ 1.5 and damp 0.005 that is the 9th try
+    h = ((q * eig) @ q.T).float()
+    h = (h + h.T) / 2
+    mean = float(h.diagonal().mean())
+    u, tries = cholesky_inverse_upper(h.cuda(), None, mean, 0.005, 50)
+    assert 2 <= tries <= 30, tries
+    s = h.double() + torch.eye(n, dtype=torch.double) * (0.005 * mean * (1.0 + 0.1 * (tries - 1)))
+    assert torch.linalg.eigvalsh(s).min() > 0
+    got = u.cpu().double()
+    resid = (got.T @ got @ s - torch.eye(n, dtype=torch.double)).abs().max().item()
+    assert resid < 5e-2, resid
+    with pytest.raises(AssertionError):
+        cholesky_inverse_upper(h.cuda(), None, mean, 0.005, 2)
 
 
 @pytest.mark.parametrize("tag", sorted(GQ.meta))
