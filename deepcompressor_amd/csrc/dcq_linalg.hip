@@ -21,11 +21,11 @@ constexpr int kNb = 128;  // block size of the factorisation = GEMM tile
 
 // =============================================================================================
 // GEMM  C[M][N] = beta * C + alpha * A * B,  B row-major [K][N]; A either k-major (At[K][M]) or row-major [M][K].
-// Tile 128 x 128 per workgroup of 4 waves (2 x 2 quadrants of 64 x 64), K step 32, register-staged double buffer.
-// Optional structure: upper_only (skip tiles strictly below the diagonal of C), a_upper / b_upper (A or B is upper
-// triangular with its origin on the diagonal: the k range of a tile is clipped accordingly).
+// Tile 128 x 128 (or 64 x 64 for small problems) per workgroup of 4 waves, K step 32, register-staged double buffer.
+// Optional structure: upper_only (skip tiles strictly below the diagonal of C) and triangular operands, for which
+// the k range of a tile is clipped to the part that can be non-zero.
 // =============================================================================================
-constexpr int kGT = 128, kGK = 32, kGLd = kGT + 4;  // LDS row pitch 132 floats: the two half-waves hit different banks
+constexpr int kGK = 32;  // K step
 constexpr int kGemmThreads = 256;
 
 struct GemmParams {
@@ -37,133 +37,122 @@ struct GemmParams {
   int64_t ldc;
   int32_t M, N, K;
   float alpha, beta;
-  int32_t upper_only, a_upper, b_upper;
+  int32_t upper_only;  // skip the tiles strictly below the diagonal of C
+  // triangular operands: A(m, k) = 0 for k < m / for k > m; B[k][n] = 0 for k > n (origins on the diagonal)
+  int32_t k_above_m, k_below_m, k_below_n;
   int32_t tiles_m, tiles_n;
+  int32_t vec_a, vec_b;  // 16-byte accesses allowed (pointer and leading dimension aligned)
 };
 
-template <bool A_KMAJOR>
-__global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(const GemmParams p) {
-  extern __shared__ __align__(16) unsigned char gemm_smem[];
-  float(*lds)[2][kGK][kGLd] = reinterpret_cast<float(*)[2][kGK][kGLd]>(gemm_smem);  // [buffer][A|B][k][m or n]
+// One 16-byte piece of a row: `FAST` pieces are whole and aligned; otherwise every element is guarded by `limit`
+// (clamped address + select, so no lane-divergent branch and no wait between the loads).
+template <bool FAST>
+__device__ __forceinline__ float4 load_piece(const float* row, int col, int limit) {
+  if (FAST) return *reinterpret_cast<const float4*>(row + col);
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float t = row[min(col + e, limit - 1)];
+    v[e] = col + e < limit ? t : 0.0f;
+  }
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// One T x T tile of C by 4 waves (2 x 2 quadrants of T/2 x T/2, each T/64 x T/64 matrix-instruction tiles).
+// T = 128 for throughput; T = 64 spreads small problems over 4x as many compute units (latency-bound regime).
+template <bool A_KMAJOR, bool FAST, int T>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m0, int n0, int k_begin, int nk) {
+  constexpr int LD = T + 4;              // LDS row pitch: the two half-waves of a fragment read hit different banks
+  constexpr int IMG = kGK * LD;          // one operand image [k][m or n]
+  constexpr int PIECES = T / 32;         // 16-byte pieces per thread, operand and k-step
+  constexpr int F = T / 64;              // 32 x 32 tiles per wave and dimension
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
-  if (p.upper_only && tn < tm) return;
-  const int m0 = tm * kGT, n0 = tn * kGT;
-  int k_begin = 0, k_end = p.K;
-  if (p.a_upper) k_begin = max(k_begin, (m0 / kGK) * kGK);               // A[m][k] = 0 for k < m
-  if (p.b_upper) k_end = min(k_end, ((n0 + kGT + kGK - 1) / kGK) * kGK);  // B[k][n] = 0 for k > n
-  const int nk = k_end > k_begin ? (k_end - k_begin) / kGK : 0;
-
-  float4 ra[4], rb[4];
+  float4 ra[PIECES], rb[PIECES];
   // staging maps.  k-major operand: piece = (k row, 4 consecutive m/n); row-major A: piece = (m row, 4 consecutive k)
-  auto load_b = [&](int kt, float4* r) {
+  auto load_ab = [&](int kt) {
     const int k0 = k_begin + kt * kGK;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < PIECES; ++it) {
       const int id = it * kGemmThreads + tid;
-      const int kr = id >> 5, c4 = (id & 31) * 4;
-      const int n = n0 + c4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float* src = p.B + static_cast<int64_t>(k0 + kr) * p.ldb + n;
-      if (n + 3 < p.N) {
-        v = *reinterpret_cast<const float4*>(src);
-      } else {
-        if (n < p.N) v.x = src[0];
-        if (n + 1 < p.N) v.y = src[1];
-        if (n + 2 < p.N) v.z = src[2];
-      }
-      r[it] = v;
-    }
-  };
-  auto load_a = [&](int kt, float4* r) {
-    const int k0 = k_begin + kt * kGK;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int id = it * kGemmThreads + tid;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int kr = id / (T / 4), c4 = (id % (T / 4)) * 4;
+      rb[it] = load_piece<FAST>(p.B + static_cast<int64_t>(k0 + kr) * p.ldb, n0 + c4, p.N);
       if (A_KMAJOR) {
-        const int kr = id >> 5, c4 = (id & 31) * 4;
-        const int m = m0 + c4;
-        const float* src = p.A + static_cast<int64_t>(k0 + kr) * p.lda + m;
-        if (m + 3 < p.M) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (m < p.M) v.x = src[0];
-          if (m + 1 < p.M) v.y = src[1];
-          if (m + 2 < p.M) v.z = src[2];
-        }
+        ra[it] = load_piece<FAST>(p.A + static_cast<int64_t>(k0 + kr) * p.lda, m0 + c4, p.M);
       } else {
         const int mr = id >> 3, k4 = (id & 7) * 4;
-        if (m0 + mr < p.M) v = *reinterpret_cast<const float4*>(p.A + static_cast<int64_t>(m0 + mr) * p.lda + k0 + k4);
+        const int m = m0 + mr;
+        const float* row = p.A + static_cast<int64_t>(min(m, p.M - 1)) * p.lda + k0;
+        float4 v = load_piece<FAST>(row, k4, kGK);  // K is a multiple of the step: only alignment can be missing
+        if (m >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        ra[it] = v;
       }
-      r[it] = v;
     }
   };
-  auto store_ab = [&](int buf, const float4* a, const float4* b) {
+  auto store_ab = [&](int buf) {
+    float* la = lds + buf * 2 * IMG;
+    float* lb = la + IMG;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < PIECES; ++it) {
       const int id = it * kGemmThreads + tid;
-      const int kr = id >> 5, c4 = (id & 31) * 4;
-      *reinterpret_cast<float4*>(&lds[buf][1][kr][c4]) = b[it];
+      const int kr = id / (T / 4), c4 = (id % (T / 4)) * 4;
+      *reinterpret_cast<float4*>(lb + kr * LD + c4) = rb[it];
       if (A_KMAJOR) {
-        *reinterpret_cast<float4*>(&lds[buf][0][kr][c4]) = a[it];
+        *reinterpret_cast<float4*>(la + kr * LD + c4) = ra[it];
       } else {
         const int mr = id >> 3, k4 = (id & 7) * 4;
-        lds[buf][0][k4 + 0][mr] = a[it].x;
-        lds[buf][0][k4 + 1][mr] = a[it].y;
-        lds[buf][0][k4 + 2][mr] = a[it].z;
-        lds[buf][0][k4 + 3][mr] = a[it].w;
+        la[(k4 + 0) * LD + mr] = ra[it].x;
+        la[(k4 + 1) * LD + mr] = ra[it].y;
+        la[(k4 + 2) * LD + mr] = ra[it].z;
+        la[(k4 + 3) * LD + mr] = ra[it].w;
       }
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[F][F];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < F; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < F; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
   if (nk > 0) {
-    load_a(0, ra);
-    load_b(0, rb);
-    store_ab(0, ra, rb);
+    load_ab(0);
+    store_ab(0);
   }
   __syncthreads();
   const int fl = lane & 31, fh = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      load_a(kt + 1, ra);
-      load_b(kt + 1, rb);
-    }
+    const float* la = lds + (kt & 1) * 2 * IMG + fh * LD + wr * (T / 2) + fl;
+    const float* lb = lds + (kt & 1) * 2 * IMG + IMG + fh * LD + wc * (T / 2) + fl;
+    if (kt + 1 < nk) load_ab(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < kGK / 2; ++kk) {
-      float af[2], bf[2];
+      float af[F], bf[F];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) af[m] = lds[buf][0][2 * kk + fh][wr * 64 + m * 32 + fl];
+      for (int m = 0; m < F; ++m) af[m] = la[2 * kk * LD + m * 32];
 #pragma unroll
-      for (int n = 0; n < 2; ++n) bf[n] = lds[buf][1][2 * kk + fh][wc * 64 + n * 32 + fl];
+      for (int n = 0; n < F; ++n) bf[n] = lb[2 * kk * LD + n * 32];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < F; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < F; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[n], acc[m][n], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_ab(buf ^ 1, ra, rb);
+    if (kt + 1 < nk) store_ab((kt + 1) & 1);
     __syncthreads();
   }
   const int col_in = lane & 31, row_off = 4 * (lane >> 5);
+  const bool inside = m0 + T <= p.M && n0 + T <= p.N;  // uniform
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < F; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < F; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + row_off;
-        const int col = n0 + wc * 64 + n * 32 + col_in;
-        if (row < p.M && col < p.N) {
+        const int row = m0 + wr * (T / 2) + m * 32 + (r & 3) + 8 * (r >> 2) + row_off;
+        const int col = n0 + wc * (T / 2) + n * 32 + col_in;
+        if (inside || (row < p.M && col < p.N)) {
           float* c = p.C + static_cast<int64_t>(row) * p.ldc + col;
           const float v = p.alpha * acc[m][n][r];
           *c = p.beta == 0.0f ? v : p.beta * *c + v;
@@ -171,75 +160,159 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(const GemmPar
       }
 }
 
-static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s) {
-  GemmParams p = pin;
-  if (p.M <= 0 || p.N <= 0) return DCQ_OK;
-  p.tiles_m = (p.M + kGT - 1) / kGT;
-  p.tiles_n = (p.N + kGT - 1) / kGT;
-  const unsigned grid = static_cast<unsigned>(p.tiles_m) * static_cast<unsigned>(p.tiles_n);
-  constexpr size_t lds = 2 * 2 * kGK * kGLd * sizeof(float);
-  auto kern = a_kmajor ? gemm_f32_kernel<true> : gemm_f32_kernel<false>;
-  int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(lds)),
-                     "hipFuncSetAttribute(gemm LDS)");
+template <bool A_KMAJOR, int T>
+__global__ __launch_bounds__(kGemmThreads, T == 128 ? 2 : 4) void gemm_f32_kernel(const GemmParams p) {
+  extern __shared__ __align__(16) unsigned char gemm_smem[];
+  float* lds = reinterpret_cast<float*>(gemm_smem);  // [buffer][A | B][k][m or n]
+  const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+  if (p.upper_only && tn < tm) return;
+  const int m0 = tm * T, n0 = tn * T;
+  int k_begin = 0, k_end = p.K;
+  if (p.k_above_m) k_begin = max(k_begin, m0 / kGK * kGK);
+  if (p.k_below_m) k_end = min(k_end, m0 + T);
+  if (p.k_below_n) k_end = min(k_end, n0 + T);
+  const int nk = k_end > k_begin ? (k_end - k_begin) / kGK : 0;
+  // whole, aligned 16-byte pieces everywhere in this tile?  (uniform over the workgroup)
+  const bool fast = p.vec_a && p.vec_b && n0 + T <= p.N && (!A_KMAJOR || m0 + T <= p.M);
+  if (fast) {
+    gemm_tile<A_KMAJOR, true, T>(p, lds, m0, n0, k_begin, nk);
+  } else {
+    gemm_tile<A_KMAJOR, false, T>(p, lds, m0, n0, k_begin, nk);
+  }
+}
+
+template <bool A_KMAJOR, int T>
+static int launch_gemm_variant(const GemmParams& p, hipStream_t s) {
+  constexpr size_t lds = 2 * 2 * kGK * (T + 4) * sizeof(float);
+  auto kern = gemm_f32_kernel<A_KMAJOR, T>;
+  static bool configured[64] = {};
+  int dev = 0;
+  int rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
   if (rc != DCQ_OK) return rc;
+  if (dev < 0 || dev >= 64 || !configured[dev]) {
+    rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds)),
+                   "hipFuncSetAttribute(gemm LDS)");
+    if (rc != DCQ_OK) return rc;
+    if (dev >= 0 && dev < 64) configured[dev] = true;
+  }
+  const unsigned grid = static_cast<unsigned>(p.tiles_m) * static_cast<unsigned>(p.tiles_n);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemmThreads), lds, s, p);
   DCQ_LAUNCH_CHECK("gemm_f32_kernel launch");
   return DCQ_OK;
 }
 
-// =============================================================================================
-// Diagonal block: R11 = upper Cholesky factor of the 128 x 128 block (in place, strict lower part zeroed),
-// Rinv = R11^-1 (upper, row-major [128][128]).  One workgroup; the block lives in LDS.
-// info: 1-based global index of the first non-positive pivot (atomicMin so the earliest failure wins).
-// =============================================================================================
-constexpr int kPanelThreads = 256;
+static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s) {
+  GemmParams p = pin;
+  if (p.M <= 0 || p.N <= 0) return DCQ_OK;
+  p.vec_a = (reinterpret_cast<uintptr_t>(p.A) & 15u) == 0 && p.lda % 4 == 0;
+  p.vec_b = (reinterpret_cast<uintptr_t>(p.B) & 15u) == 0 && p.ldb % 4 == 0;
+  // fewer 128-tiles than twice the compute units: the problem is latency-bound, use 64-tiles
+  const int64_t big_tiles = static_cast<int64_t>((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const int T = big_tiles < 512 ? 64 : 128;
+  p.tiles_m = (p.M + T - 1) / T;
+  p.tiles_n = (p.N + T - 1) / T;
+  if (T == 64) return a_kmajor ? launch_gemm_variant<true, 64>(p, s) : launch_gemm_variant<false, 64>(p, s);
+  return a_kmajor ? launch_gemm_variant<true, 128>(p, s) : launch_gemm_variant<false, 128>(p, s);
+}
 
-__global__ __launch_bounds__(kPanelThreads) void panel_factor_kernel(float* a, int64_t lda, float* rinv, int32_t* info,
-                                                                      int32_t index_base) {
-  extern __shared__ __align__(16) float sm[];
-  float(*A)[kNb + 1] = reinterpret_cast<float(*)[kNb + 1]>(sm);                    // [128][129]
-  float(*X)[kNb + 1] = reinterpret_cast<float(*)[kNb + 1]>(sm + kNb * (kNb + 1));  // inverse
-  const int tid = threadIdx.x;
-  for (int e = tid; e < kNb * kNb; e += kPanelThreads) {
-    const int r = e / kNb, c = e % kNb;
-    A[r][c] = c >= r ? a[r * lda + c] : 0.0f;
-    X[r][c] = 0.0f;
-  }
-  __syncthreads();
-  // right-looking upper Cholesky: row j is scaled, then the trailing upper triangle is updated
-  for (int j = 0; j < kNb; ++j) {
-    const float pivot = A[j][j];
-    if (!(pivot > 0.0f)) {  // uniform: every thread reads the same pivot
-      if (tid == 0) atomicMin(info, index_base + j + 1);
-      return;
-    }
-    const float d = sqrtf(pivot);
-    __syncthreads();  // everyone has read the pivot before row j is overwritten
-    for (int c = j + tid; c < kNb; c += kPanelThreads) A[j][c] = c == j ? d : A[j][c] / d;
-    __syncthreads();
-    const int rem = kNb - 1 - j;  // trailing rows j+1 .. 127
-    for (int e = tid; e < rem * rem; e += kPanelThreads) {
-      const int r = j + 1 + e / rem, c = j + 1 + e % rem;
-      if (c >= r) A[r][c] = A[r][c] - A[j][r] * A[j][c];
-    }
-    __syncthreads();
-  }
-  // inverse of the upper triangular factor: one column per thread, back substitution
-  if (tid < kNb) {
-    const int c = tid;
-    X[c][c] = 1.0f / A[c][c];
-    for (int r = c - 1; r >= 0; --r) {
-      float acc = 0.0f;
-      for (int k = r + 1; k <= c; ++k) acc = acc + A[r][k] * X[k][c];
-      X[r][c] = -acc / A[r][r];
+// =============================================================================================
+// Diagonal block.  Gauss-Jordan on the augmented block [A | I] in registers: after the 128 elimination steps the
+// left part is R11 (upper, R11^T R11 = A) and the right part is R11^-T, whose transpose X11 = R11^-1 is written
+// into the inverse matrix.  One workgroup of 16 x 16 threads, each owning an 8 x 8 sub-block of both parts; per
+// step the pivot row travels through a double-buffered LDS row (one barrier per step).
+// info: 1-based global index of the first non-positive pivot (atomicMin: the earliest failure wins); the
+// arithmetic then continues on NaNs, which is harmless (no data-dependent addressing).
+// =============================================================================================
+constexpr int kPanelThreads = 512;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(kPanelThreads) void panel_factor_kernel(float* a, int64_t lda, float* x, int64_t ldx,
+                                                                      int32_t* info, int32_t index_base) {
+  __shared__ __align__(16) float rowbuf[2][2][kNb];  // [step parity][A part | Y part][column]
+  const int tid = threadIdx.x, tx = tid & 15, ty = (tid >> 4) & 15;
+  const int part = tid >> 8;  // waves 0-3 hold the A part, waves 4-7 the Y part: no wave executes both updates
+  f32x2 Z[8][4];
+#pragma unroll
+  for (int ii = 0; ii < 8; ++ii) {
+    const int r = 8 * ty + ii;
+    const float4 v0 = *reinterpret_cast<const float4*>(a + r * lda + 8 * tx);
+    const float4 v1 = *reinterpret_cast<const float4*>(a + r * lda + 8 * tx + 4);
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int c = 8 * tx + cc;
+      Z[ii][cc >> 1][cc & 1] = part == 0 ? (c >= r ? v[cc] : 0.0f) : (c == r ? 1.0f : 0.0f);
     }
   }
-  __syncthreads();
-  for (int e = tid; e < kNb * kNb; e += kPanelThreads) {
-    const int r = e / kNb, c = e % kNb;
-    a[r * lda + c] = A[r][c];
-    rinv[e] = X[r][c];
+  // Step j = 8 jb + jj: the owners of row j publish it UNSCALED (no arithmetic before the barrier); every thread
+  // derives 1/sqrt(pivot) itself and applies  row_r -= (a_jr / d) * (row_j / d)  to the rows below (rows at or
+  // above j get a zero multiplier instead of a mask), the owners scale their own row.  One barrier per step; the
+  // row buffer alternates so a step's readers never meet the next step's writers.
+#pragma unroll 1
+  for (int jb = 0; jb < 16; ++jb) {
+    const bool active = ty >= jb && (part == 0 ? tx >= jb : tx <= jb);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int buf = jj & 1;
+      if (ty == jb) {
+        float4* dst = reinterpret_cast<float4*>(&rowbuf[buf][part][8 * tx]);
+        dst[0] = make_float4(Z[jj][0][0], Z[jj][0][1], Z[jj][1][0], Z[jj][1][1]);
+        dst[1] = make_float4(Z[jj][2][0], Z[jj][2][1], Z[jj][3][0], Z[jj][3][1]);
+      }
+      __syncthreads();
+      if (active) {
+        const float pivot = rowbuf[buf][0][8 * jb + jj];
+        if (!(pivot > 0.0f) && tid == 255) atomicMin(info, index_base + 8 * jb + jj + 1);
+        float inv = __builtin_amdgcn_rsqf(pivot);
+        inv = inv * (1.5f - 0.5f * pivot * inv * inv);  // one Newton step: full float32 accuracy
+        const f32x2 inv2 = {inv, inv};
+        const float4 m0 = *reinterpret_cast<const float4*>(&rowbuf[buf][0][8 * ty]);
+        const float4 m1 = *reinterpret_cast<const float4*>(&rowbuf[buf][0][8 * ty + 4]);
+        const float4 c0 = *reinterpret_cast<const float4*>(&rowbuf[buf][part][8 * tx]);
+        const float4 c1 = *reinterpret_cast<const float4*>(&rowbuf[buf][part][8 * tx + 4]);
+        const bool below = ty > jb;
+        const float ninv = -inv;
+        const float mr[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        float m[8];
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) m[ii] = (ii > jj || below) ? mr[ii] * ninv : 0.0f;
+        f32x2 rc[4] = {{c0.x, c0.y}, {c0.z, c0.w}, {c1.x, c1.y}, {c1.z, c1.w}};
+#pragma unroll
+        for (int h = 0; h < 4; ++h) rc[h] = rc[h] * inv2;
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+          const f32x2 mm = {m[ii], m[ii]};
+#pragma unroll
+          for (int h = 0; h < 4; ++h) Z[ii][h] = __builtin_elementwise_fma(mm, rc[h], Z[ii][h]);
+        }
+        if (!below) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) Z[jj][h] = rc[h];
+        }
+      }
+    }
+  }
+  if (part == 0) {  // R11 in place (strict lower part zero)
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+      const int r = 8 * ty + ii;
+      float v[8];
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) v[cc] = 8 * tx + cc >= r ? Z[ii][cc >> 1][cc & 1] : 0.0f;
+      *reinterpret_cast<float4*>(a + r * lda + 8 * tx) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(a + r * lda + 8 * tx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  } else if (tx <= ty) {  // X11 = Y^T into the inverse matrix (upper; its lower part stays zero)
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int c = 8 * tx + cc;  // row of X
+      float v[8];
+#pragma unroll
+      for (int ii = 0; ii < 8; ++ii) v[ii] = 8 * ty + ii >= c ? Z[ii][cc >> 1][cc & 1] : 0.0f;
+      *reinterpret_cast<float4*>(x + c * ldx + 8 * ty) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(x + c * ldx + 8 * ty + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
   }
 }
 
@@ -290,14 +363,10 @@ __global__ void fill_kernel(float* p, int64_t n, float v) {
     p[i] = v;
 }
 
-__global__ void copy_block_kernel(const float* src, float* dst, int64_t ldd) {
-  for (int e = threadIdx.x; e < kNb * kNb; e += blockDim.x) dst[(e / kNb) * ldd + (e % kNb)] = src[e];
-}
-
 struct CholPlan {
   int64_t np;
   int nblk;
-  size_t a_bytes, x_bytes, t_bytes, rinv_bytes;
+  size_t a_bytes, x_bytes, t_bytes;
 };
 
 static CholPlan plan_chol(int64_t n) {
@@ -308,58 +377,104 @@ static CholPlan plan_chol(int64_t n) {
   c.x_bytes = c.a_bytes;
   const int64_t half = (c.nblk + 1) / 2 * kNb;
   c.t_bytes = static_cast<size_t>(half) * half * 4;
-  c.rinv_bytes = static_cast<size_t>(c.nblk) * kNb * kNb * 4;
   return c;
 }
 
-// X[lo:hi, lo:hi] = inverse of the upper triangular R[lo:hi, lo:hi] (block indices), recursively:
-// X12 = -X11 * (R12 * X22).  X starts zeroed, so the lower parts of X11 / X22 read as zeros.
-static int invert_upper(const float* R, float* X, float* T, const float* rinv, int64_t np, int lo, int hi,
-                        hipStream_t s) {
+// Factor and invert the diagonal range [lo, hi) of blocks:  A (upper, in place) -> R with R^T R = A, and
+// X = R^-1 (upper; X starts zeroed so triangular operands read zeros below their diagonal).  Recursive halves:
+//     [R11, X11] = recurse(A11)
+//     R12 = X11^T A12                 (triangular solve as a GEMM with the inverse that is needed anyway)
+//     A22 -= R12^T R12                (upper triangle only; K = size of the first half, so C is touched once)
+//     [R22, X22] = recurse(A22)
+//     X12 = -X11 (R12 X22)
+static int factor_invert(float* A, float* X, float* T, int64_t np, int lo, int hi, int32_t* info, hipStream_t s) {
   if (hi - lo == 1) {
-    hipLaunchKernelGGL(copy_block_kernel, dim3(1), dim3(256), 0, s, rinv + static_cast<int64_t>(lo) * kNb * kNb,
-                       X + (static_cast<int64_t>(lo) * kNb) * (np + 1), np);
-    DCQ_LAUNCH_CHECK("copy_block_kernel launch");
+    const int64_t off = (static_cast<int64_t>(lo) * kNb) * (np + 1);
+    hipLaunchKernelGGL(panel_factor_kernel, dim3(1), dim3(kPanelThreads), 0, s, A + off, np, X + off, np, info, lo * kNb);
+    DCQ_LAUNCH_CHECK("panel_factor_kernel launch");
     return DCQ_OK;
   }
   const int mid = lo + (hi - lo + 1) / 2;
-  int rc = invert_upper(R, X, T, rinv, np, lo, mid, s);
-  if (rc != DCQ_OK) return rc;
-  rc = invert_upper(R, X, T, rinv, np, mid, hi, s);
-  if (rc != DCQ_OK) return rc;
   const int m1 = (mid - lo) * kNb, m2 = (hi - mid) * kNb;
   const int64_t o1 = static_cast<int64_t>(lo) * kNb, o2 = static_cast<int64_t>(mid) * kNb;
-  GemmParams g{};
-  // T[m1][m2] = R12 * X22      (B = X22 upper triangular)
-  g.A = R + o1 * np + o2;
-  g.lda = np;
-  g.B = X + o2 * np + o2;
-  g.ldb = np;
-  g.C = T;
-  g.ldc = m2;
-  g.M = m1;
-  g.N = m2;
-  g.K = m2;
-  g.alpha = 1.0f;
-  g.beta = 0.0f;
-  g.b_upper = 1;
-  rc = launch_gemm(g, false, s);
+  float* a12 = A + o1 * np + o2;
+  int rc = factor_invert(A, X, T, np, lo, mid, info, s);
   if (rc != DCQ_OK) return rc;
-  // X12 = -X11 * T             (A = X11 upper triangular)
-  GemmParams h{};
-  h.A = X + o1 * np + o1;
-  h.lda = np;
-  h.B = T;
-  h.ldb = m2;
-  h.C = X + o1 * np + o2;
-  h.ldc = np;
-  h.M = m1;
-  h.N = m2;
-  h.K = m1;
-  h.alpha = -1.0f;
-  h.beta = 0.0f;
-  h.a_upper = 1;
-  return launch_gemm(h, false, s);
+  {  // R12 = X11^T A12 -> T, then copied back (a GEMM cannot overwrite an operand other blocks still read)
+    GemmParams g{};
+    g.A = X + o1 * np + o1;  // k-major operand: A'(m, k) = X11[k][m], zero for k > m
+    g.lda = np;
+    g.B = a12;
+    g.ldb = np;
+    g.C = T;
+    g.ldc = m2;
+    g.M = m1;
+    g.N = m2;
+    g.K = m1;
+    g.alpha = 1.0f;
+    g.beta = 0.0f;
+    g.k_below_m = 1;
+    rc = launch_gemm(g, true, s);
+    if (rc != DCQ_OK) return rc;
+    rc = hip_check(hipMemcpy2DAsync(a12, np * 4, T, static_cast<size_t>(m2) * 4, static_cast<size_t>(m2) * 4, m1,
+                                    hipMemcpyDeviceToDevice, s),
+                   "hipMemcpy2DAsync(R12)");
+    if (rc != DCQ_OK) return rc;
+  }
+  {  // A22 -= R12^T R12 (both operands are the rows of R12)
+    GemmParams g{};
+    g.A = a12;
+    g.lda = np;
+    g.B = a12;
+    g.ldb = np;
+    g.C = A + o2 * np + o2;
+    g.ldc = np;
+    g.M = m2;
+    g.N = m2;
+    g.K = m1;
+    g.alpha = -1.0f;
+    g.beta = 1.0f;
+    g.upper_only = 1;
+    rc = launch_gemm(g, true, s);
+    if (rc != DCQ_OK) return rc;
+  }
+  rc = factor_invert(A, X, T, np, mid, hi, info, s);
+  if (rc != DCQ_OK) return rc;
+  {  // T = R12 X22 (X22 upper: k <= n)
+    GemmParams g{};
+    g.A = a12;
+    g.lda = np;
+    g.B = X + o2 * np + o2;
+    g.ldb = np;
+    g.C = T;
+    g.ldc = m2;
+    g.M = m1;
+    g.N = m2;
+    g.K = m2;
+    g.alpha = 1.0f;
+    g.beta = 0.0f;
+    g.k_below_n = 1;
+    rc = launch_gemm(g, false, s);
+    if (rc != DCQ_OK) return rc;
+  }
+  {  // X12 = -X11 T (X11 upper: k >= m)
+    GemmParams g{};
+    g.A = X + o1 * np + o1;
+    g.lda = np;
+    g.B = T;
+    g.ldb = m2;
+    g.C = X + o1 * np + o2;
+    g.ldc = np;
+    g.M = m1;
+    g.N = m2;
+    g.K = m1;
+    g.alpha = -1.0f;
+    g.beta = 0.0f;
+    g.k_above_m = 1;
+    rc = launch_gemm(g, false, s);
+    if (rc != DCQ_OK) return rc;
+  }
+  return DCQ_OK;
 }
 
 }  // namespace dcq
@@ -375,9 +490,6 @@ int dcq_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, 
   DCQ_REQUIRE(A && B && C, DCQ_ERR_ARGUMENT, "NULL buffer");
   DCQ_REQUIRE(K % kGK == 0, DCQ_ERR_UNSUPPORTED, "K must be a multiple of %d (got %lld)", kGK, (long long)K);
   DCQ_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), DCQ_ERR_UNSUPPORTED, "size too large");
-  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-  DCQ_REQUIRE(al(A) && al(B) && lda % 4 == 0 && ldb % 4 == 0, DCQ_ERR_ARGUMENT,
-              "A, B must be 16-byte aligned with leading dimensions that are multiples of 4");
   GemmParams g{};
   g.A = A;
   g.lda = lda;
@@ -396,7 +508,7 @@ int dcq_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, 
 int64_t dcq_cholesky_workspace_bytes(int64_t n) {
   if (n <= 0) return 0;
   const CholPlan c = plan_chol(n);
-  return static_cast<int64_t>(c.a_bytes + c.x_bytes + c.t_bytes + c.rinv_bytes);
+  return static_cast<int64_t>(c.a_bytes + c.x_bytes + c.t_bytes);
 }
 
 int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U, void* workspace,
@@ -411,7 +523,6 @@ int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, f
   float* A = reinterpret_cast<float*>(ws);
   float* X = reinterpret_cast<float*>(ws + c.a_bytes);
   float* T = reinterpret_cast<float*>(ws + c.a_bytes + c.x_bytes);
-  float* rinv = reinterpret_cast<float*>(ws + c.a_bytes + c.x_bytes + c.t_bytes);
   const int64_t np = c.np;
   int rc = hip_check(hipMemsetAsync(info, 0x7f, 4, s), "hipMemsetAsync(info)");  // 0x7f7f7f7f = "no failure yet"
   if (rc != DCQ_OK) return rc;
@@ -420,52 +531,7 @@ int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, f
   DCQ_LAUNCH_CHECK("flip_pad_kernel launch");
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, s, X, np * np, 0.0f);
   DCQ_LAUNCH_CHECK("fill_kernel launch");
-  const size_t panel_lds = 2 * kNb * (kNb + 1) * 4;
-  rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_factor_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(panel_lds)),
-                 "hipFuncSetAttribute(panel LDS)");
-  if (rc != DCQ_OK) return rc;
-  for (int kb = 0; kb < c.nblk; ++kb) {
-    float* a11 = A + (static_cast<int64_t>(kb) * kNb) * (np + 1);
-    float* rk = rinv + static_cast<int64_t>(kb) * kNb * kNb;
-    hipLaunchKernelGGL(panel_factor_kernel, dim3(1), dim3(kPanelThreads), panel_lds, s, a11, np, rk, info, kb * kNb);
-    DCQ_LAUNCH_CHECK("panel_factor_kernel launch");
-    const int rest = static_cast<int>(np - (kb + 1) * kNb);
-    if (rest <= 0) break;
-    float* a12 = a11 + kNb;
-    // R12 = R11^-T * A12, in place:  A'(m, k) = Rinv11[k][m]  (k-major operand = Rinv11 as stored)
-    GemmParams g{};
-    g.A = rk;
-    g.lda = kNb;
-    g.B = a12;
-    g.ldb = np;
-    g.C = a12;
-    g.ldc = np;
-    g.M = kNb;
-    g.N = rest;
-    g.K = kNb;
-    g.alpha = 1.0f;
-    g.beta = 0.0f;
-    rc = launch_gemm(g, true, s);
-    if (rc != DCQ_OK) return rc;
-    // A22 -= R12^T * R12 on the upper triangle: both operands are the panel rows (k-major)
-    GemmParams t{};
-    t.A = a12;
-    t.lda = np;
-    t.B = a12;
-    t.ldb = np;
-    t.C = a11 + static_cast<int64_t>(kNb) * (np + 1);
-    t.ldc = np;
-    t.M = rest;
-    t.N = rest;
-    t.K = kNb;
-    t.alpha = -1.0f;
-    t.beta = 1.0f;
-    t.upper_only = 1;
-    rc = launch_gemm(t, true, s);
-    if (rc != DCQ_OK) return rc;
-  }
-  rc = invert_upper(A, X, T, rinv, np, 0, c.nblk, s);
+  rc = factor_invert(A, X, T, np, 0, c.nblk, info, s);
   if (rc != DCQ_OK) return rc;
   hipLaunchKernelGGL(flip_transpose_kernel, dim3(static_cast<unsigned>((n + 31) / 32), static_cast<unsigned>((n + 31) / 32)),
                      dim3(256), 0, s, X, np, U, n);

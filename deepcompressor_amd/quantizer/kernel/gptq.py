@@ -70,8 +70,14 @@ _workspaces: dict[torch.device, torch.Tensor] = {}
 _hessian_cache: dict = {"key": None, "value": None}
 
 
+# ... and therefore one act-order permutation and one inverse factor: kept for the most recent Hessian tensor
+# (held by reference, so its storage cannot be recycled under the key).
+_factor_cache: dict = {"key": None, "value": None}
+
+
 def clear_hessian_cache() -> None:
     _hessian_cache["key"] = _hessian_cache["value"] = None
+    _factor_cache["key"] = _factor_cache["value"] = None
 
 
 def _inputs_key(inputs: TensorCache, device: torch.device):
@@ -171,6 +177,24 @@ def cholesky_inverse_upper(hessian: torch.Tensor, perm: torch.Tensor | None, dia
     return u, tries
 
 
+def _inverse_factor_of(hessian: torch.Tensor, config: QuantGptqConfig):
+    """(dead channels, act-order permutation, its inverse, U) of a Hessian (gptq.py:199-233), memoised for the most
+    recent Hessian tensor: weights that share their inputs share all four."""
+    key = (hessian._version, config.damp_percentage, config.num_inv_tries)
+    hit = _factor_cache["key"]
+    if hit is not None and hit[0] is hessian and hit[1] == key:
+        return _factor_cache["value"]
+    _factor_cache["key"] = _factor_cache["value"] = None
+    diag = hessian.diagonal()
+    dead = diag == 0
+    diag = torch.where(dead, torch.ones_like(diag), diag)
+    perm = torch.argsort(diag, descending=True)
+    inverse_perm = torch.argsort(perm)
+    U, _ = cholesky_inverse_upper(hessian, perm, float(diag.mean()), config.damp_percentage, config.num_inv_tries)
+    _factor_cache["key"], _factor_cache["value"] = (hessian, key), (dead, perm, inverse_perm, U)
+    return _factor_cache["value"]
+
+
 @torch.no_grad()
 def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: QuantDataType,
                   zero_domain: ZeroPointDomain | None, scale: torch.Tensor, zero: torch.Tensor,
@@ -194,14 +218,8 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     # ---- Hessian (shared, never modified), dead channels, act-order permutation, damping, inverse factor
     hessian = hessian_of(inputs, dev) if hessian is None else hessian
     assert hessian.shape == (Cn, Cn), "activation channels do not match the weight's input channels"
-    diag = hessian.diagonal()
-    dead = diag == 0
-    diag = torch.where(dead, torch.ones_like(diag), diag)
-    perm = torch.argsort(diag, descending=True)
+    dead, perm, inverse_perm, U = _inverse_factor_of(hessian, gptq_config)
     W = torch.where(dead, torch.zeros((), device=dev, dtype=W.dtype), W)[:, perm].contiguous()
-    inverse_perm = torch.argsort(perm)
-    diag_mean = float(diag.mean())
-    U, _ = cholesky_inverse_upper(hessian, perm, diag_mean, gptq_config.damp_percentage, gptq_config.num_inv_tries)
     # ---- sweep
     qr = QuantRange.construct(quant_dtype, has_zero_point=zero_domain is not None, quant_range=quant_range)
     step = engine.make_step(quant_dtype=quant_dtype, zero_domain=zero_domain, tensor_quant_range=qr,
@@ -217,7 +235,6 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
             z2 = zero.to(torch.float32).reshape(n_rg, n_cg).contiguous()
     Q = torch.zeros_like(W)
     err = torch.empty((R, SWEEP_COLUMNS), device=dev, dtype=torch.float32)
-    U = U.contiguous()
     stream = stream_of(dev)
     for c0 in range(0, Cn, SWEEP_COLUMNS):
         bc = min(SWEEP_COLUMNS, Cn - c0)

@@ -233,7 +233,7 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
  *
  * dcq_gemm_f32: C[M][N] = beta * C + alpha * A * B with B row-major [K][N] (ldb) and A either row-major
  * [M][K] (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1), leading dimension lda.  K must be a
- * multiple of 32; A, B 16-byte aligned with lda, ldb multiples of 4.  Replaces the lazy update
+ * multiple of 32; 16-byte aligned A, B with lda, ldb multiples of 4 take the fast load path.  Replaces the lazy update
  * `W[:, c_end:] -= Err @ U[c0:c_end, c_end:]` (gptq.py:269) and is the building block of the routine below.
  *
  * dcq_cholesky_inverse_upper: U[n][n] (upper triangular, row-major) with U^T U = S^-1 where

@@ -43,18 +43,19 @@ def test_hessian_matches_float64(T, C, dt):
 
 
 @pytest.mark.parametrize("M,N,K,a_t", [(128, 128, 32, False), (96, 200, 128, False), (300, 515, 64, True),
-                                       (1024, 2048, 128, False), (257, 129, 256, True), (4, 4, 32, False)])
+                                       (1024, 2048, 128, False), (257, 129, 256, True), (4, 4, 32, False), (131, 77, 64, True), (131, 77, 64, False),
+                                       (2950, 3075, 64, False), (2950, 3076, 32, True)])
 def test_gemm_f32_matches_float64(M, N, K, a_t):
     """c = beta c + alpha a b on the float32 matrix-core path: ragged M / N edges, both A layouts, strided views."""
     g = torch.Generator().manual_seed(M * 7 + N)
     a = torch.randn(M, K, generator=g)
-    b_full = torch.randn(K, (N + 12 + 3) // 4 * 4, generator=g)  # leading dimensions must be multiples of 4
+    b_full = torch.randn(K, N + 12 if N == 77 else (N + 12 + 3) // 4 * 4, generator=g)  # N = 77: unaligned load path
     c_full = torch.randn(M, N + 8, generator=g)
     b, c = b_full[:, 12:12 + N], c_full[:, 8:]  # column offsets keep 16-byte alignment but make the views strided
     want = 0.5 * c.double() - 1.25 * (a.double() @ b.double())
     a_dev = a.cuda()
     if a_t:
-        a_dev = torch.zeros(K, (M + 3) // 4 * 4, device="cuda")[:, :M].copy_(a.T)
+        a_dev = torch.zeros(K, M if N == 77 else (M + 3) // 4 * 4, device="cuda")[:, :M].copy_(a.T)
     b_dev, c_dev = b_full.cuda(), c_full.cuda()
     gemm_f32(a_dev, b_dev[:, 12:12 + N], c_dev[:, 8:], alpha=-1.25, beta=0.5, a_transposed=a_t)
     got = c_dev.cpu()

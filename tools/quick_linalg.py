@@ -1,0 +1,39 @@
+"""GPU timing of the float32 GEMM and the inverse-factor routine: python tools/quick_linalg.py"""
+import sys
+import torch
+sys.path.insert(0, ".")
+from deepcompressor_amd.quantizer.kernel.gptq import cholesky_inverse_upper, gemm_f32
+
+
+def timed(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+only_inv = len(sys.argv) > 1 and sys.argv[1] == "inv"
+sizes = [int(v) for v in sys.argv[2:]] if only_inv else (128, 1024, 4096, 14336)
+for (M, N, K, at) in [] if only_inv else [(4096, 14208, 128, False), (14336, 3968, 128, False), (4096, 4096, 128, False),
+                      (7168, 7168, 7168, False), (7168, 7168, 7168, True), (2048, 2048, 2048, True),
+                      (1024, 1024, 1024, True), (512, 512, 512, False), (128, 14208, 128, True), (128, 128, 128, True)]:
+    a = torch.randn((K, M) if at else (M, K), device="cuda")
+    b = torch.randn(K, N, device="cuda")
+    c = torch.randn(M, N, device="cuda")
+    ms = timed(lambda: gemm_f32(a, b, c, alpha=-1.0, beta=1.0, a_transposed=at))
+    ms_t = timed(lambda: c.addmm_(a.T if at else a, b, alpha=-1.0))
+    print(f"gemm M={M} N={N} K={K} at={at}: {ms*1e3:9.1f} us {2*M*N*K/ms/1e9:7.1f} TF/s | torch addmm {ms_t*1e3:9.1f} us "
+          f"{2*M*N*K/ms_t/1e9:7.1f} TF/s", flush=True)
+
+for n in sizes:
+    x = torch.randn(2 * n, n, device="cuda")
+    h = (x.T @ x) / n
+    del x
+    mean = float(h.diagonal().mean())
+    ms = timed(lambda: cholesky_inverse_upper(h, None, mean, 0.01, 3), reps=3)
+    print(f"inverse factor n={n}: {ms:9.3f} ms  ({(2/3)*n**3/ms/1e9:6.1f} TF/s on 2/3 n^3)", flush=True)
