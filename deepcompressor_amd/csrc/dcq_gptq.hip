@@ -64,23 +64,26 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* __re
 }
 
 // =============================================================================================
-// SYRK on MFMA: tile 128 x 128, K step 64, 4 waves (2 x 2 quadrants of 64 x 64), 32x32x16 instructions.
+// SYRK on MFMA: tile 256 x 256, K step 64, 8 waves (2 x 4 grid of 128 x 64 sub-tiles), 32x32x16 instructions.
+// A 256-tile needs 128 flop per operand byte fetched from L2, twice what a 128-tile does: at the matrix-core peak
+// the chip-wide L2 -> LDS stream of 128-tiles would be ~39 TB/s, about twice what the L2s deliver.
 //
 // Operand tiles go HBM/L2 -> LDS directly (global_load_lds, 16 B per lane, no VGPR staging).  The LDS image
-// of a tile is row-major [128 rows][8 chunks of 16 B]; one wave-instruction fills 8 consecutive rows, its 8
+// of a tile is row-major [256 rows][8 chunks of 16 B]; one wave-instruction fills 8 consecutive rows, its 8
 // lanes per row fetch one full 128-byte line.  To keep the 16-byte fragment reads conflict-free the chunk
 // position is XOR-swizzled with bits 1..3 of the row; direct-to-LDS writes are lane-linear, so the swizzle is
 // applied to the *global source* chunk and again on the read.
 //
-// Workgroups are renumbered so that the 64 workgroups resident on one XCD (blockIdx = xcd mod 8) cover one
-// 8 x 8 patch of output tiles: every row/column panel streamed from memory is then shared by 8 workgroups
+// Workgroups are renumbered so that the workgroups resident on one XCD (blockIdx = xcd mod 8) walk one
+// 8 x 8 patch of output tiles: every row/column panel streamed from memory is then shared by several workgroups
 // through that XCD's L2.
 // =============================================================================================
-constexpr int kTile = 128;
+constexpr int kTile = 256;
 constexpr int kBK = 64;
 constexpr int kRowBytes = kBK * 2;                // 128 B per tile row
-constexpr int kOperandBytes = kTile * kRowBytes;  // 16 KiB
-constexpr int kSyrkThreads = 256;
+constexpr int kOperandBytes = kTile * kRowBytes;  // 32 KiB
+constexpr int kSyrkThreads = 512;
+constexpr int kSyrkMT = 4, kSyrkNT = 2;           // 32 x 32 tiles per wave: 128 rows x 64 columns
 constexpr int kPatch = 8;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -107,7 +110,7 @@ struct SyrkParams {
   const uint16_t* xt;  // [Cp][Tp]
   int64_t Tp;
   int32_t C, Cp;
-  int32_t tiles_per_side;  // Cp / 128
+  int32_t tiles_per_side;  // Cp / 256
   int32_t num_tiles;       // upper triangle incl. diagonal
   int32_t splits;          // K splits
   int32_t ktiles_per_split;
@@ -151,11 +154,11 @@ __global__ void syrk_tile_map_kernel(int2* map, int n, int num_tiles) {
 }
 
 template <int ST>
-__global__ __launch_bounds__(kSyrkThreads, 2) void syrk_kernel(const SyrkParams p) {
-  extern __shared__ __align__(1024) unsigned char lds[];  // [2 buffers][A, B][16 KiB]
+__global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams p) {
+  extern __shared__ __align__(1024) unsigned char lds[];  // [2 buffers][A, B][32 KiB]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;  // wave's 64 x 64 quadrant
+  const int wr = wave >> 2, wc = wave & 3;  // wave's 128 x 64 sub-tile
   // XCD-aware renumbering (bijective for any grid size): consecutive logical ids stay on one XCD
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r8 = nwg & 7;
   const int logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
@@ -164,6 +167,8 @@ __global__ __launch_bounds__(kSyrkThreads, 2) void syrk_kernel(const SyrkParams 
   const int2 t = p.tile_map[tile_idx];
   const int bi = t.x, bj = t.y;
   const bool diag = bi == bj;
+  // on a diagonal tile the sub-tiles strictly below the diagonal are never stored: their waves only stage
+  const bool computes = !diag || wc * 64 + 64 > wr * 128;
 
   const int64_t k_begin = static_cast<int64_t>(split) * p.ktiles_per_split * kBK;
   int64_t k_end = k_begin + static_cast<int64_t>(p.ktiles_per_split) * kBK;
@@ -192,11 +197,11 @@ __global__ __launch_bounds__(kSyrkThreads, 2) void syrk_kernel(const SyrkParams 
     }                                                                                           \
   } while (0)
 
-  f32x16 acc[2][2];
+  f32x16 acc[kSyrkMT][kSyrkNT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < kSyrkMT; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < kSyrkNT; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
@@ -204,60 +209,69 @@ __global__ __launch_bounds__(kSyrkThreads, 2) void syrk_kernel(const SyrkParams 
   __syncthreads();
   // fragment addressing: lane -> tile row (lane & 31), k-chunk (2 ks + (lane >> 5)), swizzled position
   const int frag_row = lane & 31, frag_half = lane >> 5;
-  int a_off[2], b_off[2], a_sw[2], b_sw[2];
+  int a_off[kSyrkMT], a_sw[kSyrkMT], b_off[kSyrkNT], b_sw[kSyrkNT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int ra = wr * 64 + m * 32 + frag_row, rb = wc * 64 + m * 32 + frag_row;
+  for (int m = 0; m < kSyrkMT; ++m) {
+    const int ra = wr * 128 + m * 32 + frag_row;
     a_off[m] = ra * kRowBytes;
     a_sw[m] = (ra >> 1) & 7;
-    b_off[m] = rb * kRowBytes;
-    b_sw[m] = (rb >> 1) & 7;
+  }
+#pragma unroll
+  for (int n = 0; n < kSyrkNT; ++n) {
+    const int rb = wc * 64 + n * 32 + frag_row;
+    b_off[n] = rb * kRowBytes;
+    b_sw[n] = (rb >> 1) & 7;
   }
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) DCQ_STAGE(buf ^ 1, kt + 1);
     const unsigned char* a_lds = lds + buf * 2 * kOperandBytes;
     const unsigned char* b_lds = diag ? a_lds : a_lds + kOperandBytes;
+    if (computes) {
 #pragma unroll
-    for (int ks = 0; ks < kBK / 16; ++ks) {
-      const int chunk = ks * 2 + frag_half;
-      uint4 af[2], bf[2];
+      for (int ks = 0; ks < kBK / 16; ++ks) {
+        const int chunk = ks * 2 + frag_half;
+        uint4 af[kSyrkMT], bf[kSyrkNT];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) af[m] = *reinterpret_cast<const uint4*>(a_lds + a_off[m] + ((chunk ^ a_sw[m]) << 4));
+        for (int m = 0; m < kSyrkMT; ++m)
+          af[m] = *reinterpret_cast<const uint4*>(a_lds + a_off[m] + ((chunk ^ a_sw[m]) << 4));
 #pragma unroll
-      for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const uint4*>(b_lds + b_off[n] + ((chunk ^ b_sw[n]) << 4));
+        for (int n = 0; n < kSyrkNT; ++n)
+          bf[n] = *reinterpret_cast<const uint4*>(b_lds + b_off[n] + ((chunk ^ b_sw[n]) << 4));
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < kSyrkMT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = mfma_32x32x16<ST>(af[m], bf[n], acc[m][n]);
+          for (int n = 0; n < kSyrkNT; ++n) acc[m][n] = mfma_32x32x16<ST>(af[m], bf[n], acc[m][n]);
+      }
     }
     __syncthreads();  // drains the direct-to-LDS loads of tile kt + 1 and fences the reads of tile kt
   }
 #undef DCQ_STAGE
+  if (!computes) return;
 
   // epilogue.  C/D layout of the 32x32 instruction: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int col_in = lane & 31, row_off = 4 * (lane >> 5);
   if (p.splits > 1) {
     float* slab = p.partial + (static_cast<int64_t>(split) * p.num_tiles + tile_idx) * (kTile * kTile);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < kSyrkMT; ++m)
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int n = 0; n < kSyrkNT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + row_off;
+          const int row = wr * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + row_off;
           const int col = wc * 64 + n * 32 + col_in;
           slab[row * kTile + col] = acc[m][n][r];
         }
     return;
   }
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < kSyrkMT; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < kSyrkNT; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = bi * kTile + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + row_off;
+        const int row = bi * kTile + wr * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + row_off;
         const int col = bj * kTile + wc * 64 + n * 32 + col_in;
         if (row < p.C && col < p.C) {
           const float v = p.alpha * acc[m][n][r];
@@ -308,9 +322,21 @@ static HessianPlan plan_hessian(int64_t T, int64_t C) {
   h.tiles_side = static_cast<int>(h.Cp / kTile);
   h.num_tiles = h.tiles_side * (h.tiles_side + 1) / 2;
   const int ktiles = static_cast<int>(h.Tp / kBK);
-  // two workgroups fit per CU: aim for >= 4 rounds of 512 resident workgroups, keep >= 32 k-tiles per split
+  // one workgroup per compute unit: pick the K split whose workgroup count fills whole rounds of 256 best,
+  // with at least 32 k-tiles per split and at most 1.5 GB of partial slabs
   int splits = 1;
-  while (static_cast<int64_t>(h.num_tiles) * splits < 2048 && ktiles / (splits * 2) >= 32 && splits < 64) splits *= 2;
+  double best = 0.0;
+  for (int sp = 1; sp <= 64; ++sp) {
+    if (sp > 1 && ktiles / sp < 32) break;
+    const int64_t wgs = static_cast<int64_t>(h.num_tiles) * sp;
+    const int64_t rounds = (wgs + 255) / 256;
+    if (sp > 1 && wgs * kTile * kTile * 4 > (3ll << 29)) break;
+    const double eff = static_cast<double>(wgs) / static_cast<double>(rounds * 256);
+    if (eff > best + 0.02) {
+      best = eff;
+      splits = sp;
+    }
+  }
   h.splits = splits;
   h.ktiles_per_split = (ktiles + splits - 1) / splits;
   h.xt_bytes = static_cast<size_t>(round_up(h.Cp * h.Tp * 2, 256));

@@ -22,5 +22,5 @@ for C in Cs:
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
     t = min(ms)
-    nt = (C // 128) * (C // 128 + 1) // 2
-    print(f"C={C} T={T}: syrk {t:.2f} ms  algorithmic {2*T*C*C/t/1e9:.0f} TF  executed {2*T*nt*128*128/t/1e9:.0f} TF  relerr {err:.2e}")
+    nt = ((C + 255) // 256) * ((C + 255) // 256 + 1) // 2
+    print(f"C={C} T={T}: syrk {t:.2f} ms  algorithmic {2*T*C*C/t/1e9:.0f} TF  executed {2*T*nt*256*256/t/1e9:.0f} TF  relerr {err:.2e}")
