@@ -101,10 +101,22 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(const uint4& a, const uint4& b, 
   }
 }
 
+// Direct-to-LDS load of 16 B per lane: the wave's 64 pieces land lane-linearly at `lds_wave_base` (M0).  Issued as
+// inline assembly on purpose: through the builtin the compiler treats the LDS write as aliasing every later LDS
+// read and drains the load (vmcnt(0)) before the first fragment read, which serialises the fetch of k-tile
+// kt + 1 with the arithmetic of k-tile kt.  The caller owns the ordering instead: wait_direct_loads() + barrier
+// before the filled buffer is read, and never a read of the buffer being filled.
 __device__ __forceinline__ void load_to_lds_16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),
-                                   (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
+  // wave-uniform by construction; readfirstlane makes that visible to the compiler (M0 takes a scalar)
+  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void*)(lds_wave_base))));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory", "m0");
 }
+
+__device__ __forceinline__ void wait_direct_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0) only
 
 struct SyrkParams {
   const uint16_t* xt;  // [Cp][Tp]
@@ -206,6 +218,7 @@ __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams 
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
   if (nk > 0) DCQ_STAGE(0, 0);
+  wait_direct_loads();
   __syncthreads();
   // fragment addressing: lane -> tile row (lane & 31), k-chunk (2 ks + (lane >> 5)), swizzled position
   const int frag_row = lane & 31, frag_half = lane >> 5;
@@ -244,7 +257,8 @@ __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams 
           for (int n = 0; n < kSyrkNT; ++n) acc[m][n] = mfma_32x32x16<ST>(af[m], bf[n], acc[m][n]);
       }
     }
-    __syncthreads();  // drains the direct-to-LDS loads of tile kt + 1 and fences the reads of tile kt
+    wait_direct_loads();  // tile kt + 1 has landed (this wave's pieces) ...
+    __syncthreads();      // ... and everyone's; also fences the reads of tile kt
   }
 #undef DCQ_STAGE
   if (!computes) return;
