@@ -171,8 +171,8 @@ def main() -> None:
         # computes it); the kernel executes the upper-triangular tiles only.
         syrk_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in syrk_events)
         syrk_flop = sum(2.0 * args.tokens * c * c for _, _, c in syrk_events)
-        tiles = lambda c: (-(-c // 128)) * (-(-c // 128) + 1) // 2  # noqa: E731
-        exec_flop = sum(2.0 * args.tokens * tiles(c) * 128 * 128 for _, _, c in syrk_events)
+        tiles = lambda c: (-(-c // 256)) * (-(-c // 256) + 1) // 2  # noqa: E731
+        exec_flop = sum(2.0 * args.tokens * tiles(c) * 256 * 256 for _, _, c in syrk_events)
         achieved = syrk_flop / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
         line = {
             "metric": "quantized params/sec (whole node), Llama-3-8B GPTQ W4 g128 + range search",

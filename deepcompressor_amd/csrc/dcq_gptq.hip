@@ -299,23 +299,39 @@ __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams 
       }
 }
 
-// H[tile] += alpha * sum_s partial[s][tile]  (fixed order), mirrored
+// H[tile] += alpha * sum_s partial[s][tile]  (fixed order), mirrored.  16 workgroups per tile, 16 rows each;
+// one thread sums 4 consecutive columns (16-byte slab reads).
+constexpr int kReduceRows = 16;
+
 __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkParams p) {
-  const int tile_idx = blockIdx.x;
+  const int tile_idx = blockIdx.x / (kTile / kReduceRows);
+  const int r0 = (blockIdx.x % (kTile / kReduceRows)) * kReduceRows;
   const int2 t = p.tile_map[tile_idx];
   const int bi = t.x, bj = t.y;
-  for (int e = threadIdx.x; e < kTile * kTile; e += 256) {
-    const int r = e / kTile, c = e % kTile;
+  for (int e = threadIdx.x; e < kReduceRows * (kTile / 4); e += 256) {
+    const int r = r0 + e / (kTile / 4), c = (e % (kTile / 4)) * 4;
     const int row = bi * kTile + r, col = bj * kTile + c;
     if (row >= p.C || col >= p.C) continue;
-    if (bi == bj && col < row) continue;
-    float s = 0.0f;
-    for (int sp = 0; sp < p.splits; ++sp)
-      s = s + p.partial[(static_cast<int64_t>(sp) * p.num_tiles + tile_idx) * (kTile * kTile) + e];
-    float* h = p.H + static_cast<int64_t>(row) * p.C + col;
-    const float sum = *h + p.alpha * s;
-    *h = sum;
-    if (col != row) p.H[static_cast<int64_t>(col) * p.C + row] = sum;
+    if (bi == bj && c + 3 < r) continue;  // entirely below the diagonal
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sp = 0; sp < p.splits; ++sp) {
+      const float4 v = *reinterpret_cast<const float4*>(
+          p.partial + (static_cast<int64_t>(sp) * p.num_tiles + tile_idx) * (kTile * kTile) + r * kTile + c);
+      s4.x = s4.x + v.x;
+      s4.y = s4.y + v.y;
+      s4.z = s4.z + v.z;
+      s4.w = s4.w + v.w;
+    }
+    const float s[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cc = col + i;
+      if (cc >= p.C || (bi == bj && cc < row)) continue;
+      float* h = p.H + static_cast<int64_t>(row) * p.C + cc;
+      const float sum = *h + p.alpha * s[i];
+      *h = sum;
+      if (cc != row) p.H[static_cast<int64_t>(cc) * p.C + row] = sum;
+    }
   }
 }
 
@@ -383,7 +399,8 @@ struct SweepParams {
   int32_t has_bound_min, has_bound_max;
   float bound_min, bound_max;
   float* Q;    // [R][ldw] codes, permuted order
-  float* Err;  // [R][128]
+  float* Err;  // [R][ld_err], 128 columns used
+  int64_t ld_err;
 };
 
 template <int ZD, bool INT_Q>
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(kSweepThreads) void gptq_sweep_kernel(const SweepPa
       for (int i = 0; i < kSweepPerLane; ++i) {
         const int col = tl * kSweepPerLane + i;
         if (col < p.bc) p.Q[row * p.ldw + p.c0 + col] = q[i];
-        p.Err[row * kSweepCols + col] = col < p.bc ? er[i] : 0.0f;
+        p.Err[row * p.ld_err + col] = col < p.bc ? er[i] : 0.0f;
       }
     }
   }
@@ -541,7 +558,8 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
   g_prof_start = g_prof_stop = nullptr;
   DCQ_LAUNCH_CHECK("syrk_kernel launch");
   if (h.splits > 1) {
-    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(static_cast<unsigned>(h.num_tiles)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(static_cast<unsigned>(h.num_tiles) * (kTile / kReduceRows)), dim3(256), 0, s,
+                       p);
     DCQ_LAUNCH_CHECK("syrk_reduce_kernel launch");
   }
   return DCQ_OK;
@@ -550,7 +568,7 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
 int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64_t C, const float* U, int32_t c0,
                          int32_t bc, const float* scale, const float* zero, float zero_scalar, int32_t row_group_size,
                          int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
-                         dcq_stream_t stream) {
+                         int64_t ld_err, dcq_stream_t stream) {
   DCQ_REQUIRE(step != nullptr, DCQ_ERR_ARGUMENT, "step is NULL");
   DCQ_REQUIRE(step->tensor.kind == DCQ_ROUND_INT || step->tensor.kind == DCQ_ROUND_CODEBOOK, DCQ_ERR_UNSUPPORTED,
               "tensor dtype must be an integer or a codebook type");
@@ -560,6 +578,7 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
   DCQ_REQUIRE(bc >= 1 && bc <= kSweepCols && c0 >= 0 && c0 + bc <= C, DCQ_ERR_ARGUMENT,
               "bad block [%d, %d) for C=%lld (at most 128 columns per call)", c0, c0 + bc, (long long)C);
   DCQ_REQUIRE(row_group_size >= 1 && col_group_size >= 1 && col_groups >= 1, DCQ_ERR_ARGUMENT, "bad group geometry");
+  DCQ_REQUIRE(ld_err >= kSweepCols, DCQ_ERR_ARGUMENT, "ld_err must be at least 128");
   SweepParams p{};
   p.step = *step;
   p.W = W;
@@ -582,6 +601,7 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
   p.bound_max = step->bound_max;
   p.Q = Q;
   p.Err = Err;
+  p.ld_err = ld_err;
   const size_t lds = kSweepCols * kSweepCols * 4 + 256 * 4;
   const int rows_per_block = kSweepThreads / kSweepTeam;
   int64_t blocks = (R + rows_per_block - 1) / rows_per_block;

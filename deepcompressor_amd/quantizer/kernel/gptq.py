@@ -27,6 +27,7 @@ from ..config.kernel import BaseQuantKernel, BaseQuantKernelConfig
 __all__ = ["QuantGptqConfig", "QuantGptqKernel", "gptq_quantize", "hessian_accumulate", "hessian_of",
            "clear_hessian_cache", "cholesky_inverse_upper", "gemm_f32"]
 
+LAZY_BLOCKS = 4  # sweep blocks per far-column update
 SWEEP_COLUMNS = 128  # columns per sweep launch; the result does not depend on the block width (only fp order does)
 
 
@@ -234,16 +235,27 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
         else:
             z2 = zero.to(torch.float32).reshape(n_rg, n_cg).contiguous()
     Q = torch.zeros_like(W)
-    err = torch.empty((R, SWEEP_COLUMNS), device=dev, dtype=torch.float32)
+    # Lazy updates at two levels (same sums as gptq.py:269, regrouped): the errors of LAZY_BLOCKS consecutive
+    # sweep blocks are collected side by side; columns inside the group are updated after every block (K = 128),
+    # the columns right of the group once per group with one K = 128 * LAZY_BLOCKS product, which reads and
+    # writes the far part of W LAZY_BLOCKS times less often.
+    group_cols = SWEEP_COLUMNS * LAZY_BLOCKS
+    err = torch.empty((R, group_cols), device=dev, dtype=torch.float32)
     stream = stream_of(dev)
-    for c0 in range(0, Cn, SWEEP_COLUMNS):
-        bc = min(SWEEP_COLUMNS, Cn - c0)
-        check(lib().dcq_gptq_sweep_block(C.byref(step), ptr(W), Cn, R, Cn, ptr(U), c0, bc, ptr(s2), ptr(z2), z_scalar,
-                                         rg_size, cg_size, n_cg, ptr(perm), ptr(Q), ptr(err), stream),
-              "dcq_gptq_sweep_block")
-        c_end = c0 + bc
-        if c_end < Cn:  # lazy update of everything right of the block
-            gemm_f32(err, U[c0:c_end, c_end:], W[:, c_end:], alpha=-1.0, beta=1.0)
+    raw = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for g0 in range(0, Cn, group_cols):
+        g_end = min(g0 + group_cols, Cn)
+        for c0 in range(g0, g_end, SWEEP_COLUMNS):
+            bc = min(SWEEP_COLUMNS, Cn - c0)
+            err_block = err[:, c0 - g0:c0 - g0 + SWEEP_COLUMNS]
+            check(lib().dcq_gptq_sweep_block(C.byref(step), ptr(W), Cn, R, Cn, ptr(U), c0, bc, ptr(s2), ptr(z2),
+                                             z_scalar, rg_size, cg_size, n_cg, ptr(perm), ptr(Q), raw(err_block),
+                                             group_cols, stream), "dcq_gptq_sweep_block")
+            c_end = c0 + bc
+            if c_end < g_end:  # the rest of this group, right away
+                gemm_f32(err_block, U[c0:c_end, c_end:g_end], W[:, c_end:g_end], alpha=-1.0, beta=1.0)
+        if g_end < Cn:  # everything right of the group, once (a full group: its blocks are all 128 wide)
+            gemm_f32(err, U[g0:g_end, g_end:], W[:, g_end:], alpha=-1.0, beta=1.0)
     Q = Q[:, inverse_perm]
     assert not Q.isnan().any(), "GPTQ Quantized tensor contains NaN."
     assert not Q.isinf().any(), "GPTQ Quantized tensor contains Inf."

@@ -210,8 +210,10 @@ int dcq_selftest_division(const float* x, const float* s, float* fast, float* re
  * H^-1 in permuted order.  For each column c of the block and each row: clamp to the step's RangeBound,
  * quantize with the scale/zero of original column group perm[c] / col_group_size (gptq.py:246-259),
  * error = (w - dequant) / U[c][c], and W[:, c+1 : c0+bc] -= error * U[c][c+1 : c0+bc].  Outputs the codes
- * Q[R][ldw] (permuted column order, block columns only) and Err[R][128] for the caller's lazy update
- * W[:, c0+bc:] -= Err @ U[c0:c0+bc, c0+bc:] (gptq.py:269).  scale/zero: [R / row_group_size][col_groups].
+ * Q[R][ldw] (permuted column order, block columns only) and Err[R][ld_err] (128 columns written, zeros past bc)
+ * for the caller's lazy update W[:, c0+bc:] -= Err @ U[c0:c0+bc, c0+bc:] (gptq.py:269); ld_err > 128 lets the
+ * caller collect the errors of several blocks side by side and update far columns with one larger product.
+ * scale/zero: [R / row_group_size][col_groups].
  * ------------------------------------------------------------------------------------------- */
 int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C);
 
@@ -226,7 +228,7 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
 int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64_t C, const float* U, int32_t c0,
                          int32_t bc, const float* scale, const float* zero, float zero_scalar, int32_t row_group_size,
                          int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
-                         dcq_stream_t stream);
+                         int64_t ld_err, dcq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense float32 linear algebra of GPTQ on the matrix cores.
