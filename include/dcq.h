@@ -34,7 +34,7 @@ enum dcq_status {
 };
 
 /* storage type of a tensor in memory */
-enum dcq_storage { DCQ_F32 = 0, DCQ_F16 = 1, DCQ_BF16 = 2 };
+enum dcq_storage { DCQ_F32 = 0, DCQ_F16 = 1, DCQ_BF16 = 2, DCQ_F64 = 3 /* dcq_gemm_f64 operands only */ };
 
 /* deepcompressor/data/zero.py:9-13 */
 enum dcq_zero_domain { DCQ_ZERO_NONE = 0, DCQ_ZERO_PRE_SCALE = 1, DCQ_ZERO_POST_SCALE = 2 };
@@ -254,6 +254,22 @@ int64_t dcq_cholesky_workspace_bytes(int64_t n);
 
 int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U, void* workspace,
                                int64_t workspace_bytes, int32_t* info, dcq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rotation (deepcompressor/calib/rotate.py:66-133, utils/math/hadamard.py:48-61).
+ *
+ * dcq_gemm_f64: C_b[M][N] = A_b * B_b for b < batch, accumulated in float64 on the matrix cores.  Every operand
+ * has its own storage type (DCQ_F64 / DCQ_F32 / DCQ_F16 / DCQ_BF16): inputs are widened exactly, the result is
+ * rounded double -> float -> storage, which is what `Tensor.to(dtype)` does to a float64 tensor.  B is
+ * row-major [K][N]; A is row-major [M][K] (a_kmajor = 0) or stored transposed [K][M] (a_kmajor = 1).  Batch
+ * strides are in elements (0 = shared operand).  One call replaces
+ *   `matmul(weight.view(-1, n).to(float64), rotation).to(dtype)`                  rotate_in_channels  (rotate.py:66-73)
+ *   `matmul(rotation.T, weight.view(heads, hc, -1).to(float64)).to(dtype)`        rotate_out_channels (rotate.py:76-95)
+ *   `x.view(-1, k, n/k) @ hadamard_rhs`, `hadamard_lhs @ x`                       hardmard_transform  (hadamard.py:48-61)
+ * ------------------------------------------------------------------------------------------- */
+int dcq_gemm_f64(const void* A, int32_t a_storage, int64_t lda, int32_t a_kmajor, int64_t a_batch_stride, const void* B,
+                 int32_t b_storage, int64_t ldb, int64_t b_batch_stride, void* C, int32_t c_storage, int64_t ldc,
+                 int64_t c_batch_stride, int64_t M, int64_t N, int64_t K, int64_t batch, dcq_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -277,11 +277,69 @@ def gen_gptq(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+def gen_rotate(ref) -> None:
+    """Hadamard tables, rotation matrices and rotated weights from the reference's own functions
+    (deepcompressor/calib/rotate.py, utils/math/hadamard.py) on small seeded inputs."""
+    import torch.nn as nn
+    from deepcompressor.calib import rotate as rrot
+    from deepcompressor.utils.math.hadamard import HadamardMatrix, hardmard_transform, random_hadamard_matrix
+
+    arrays, meta = {}, {}
+    for k in (12, 20, 28, 36, 40, 52, 60, 108, 140, 156, 172):
+        h = HadamardMatrix._get_hadamard_k(k).numpy()
+        arrays[f"hadamard|{k}"] = np.packbits(h > 0)
+    g = torch.Generator().manual_seed(77)
+    cases = [("n64_bf16", 48, 64, "bf16"), ("n96_f16", 40, 96, "f16"), ("n224_bf16", 24, 224, "bf16"),
+             ("n512_f32", 16, 512, "f32")]
+    for tag, rows, n, dt in cases:
+        w = (torch.randn(rows, n, generator=g) * 0.05).to(TORCH_DT[dt])
+        arrays[f"{tag}|w"] = _np(w)
+        fixed = rrot.get_rotation_matrix(n, random=False)
+        torch.manual_seed(1000 + n)
+        rand = rrot.get_rotation_matrix(n, random=True)
+        arrays[f"{tag}|rotation_fixed"] = fixed.numpy()
+        arrays[f"{tag}|rotation_random"] = rand.numpy()
+        for name, rot in (("fixed", fixed), ("random", rand)):
+            p = nn.Parameter(w.clone(), requires_grad=False)
+            rrot.rotate_in_channels(p, rotation=rot)
+            arrays[f"{tag}|in_{name}"] = _np(p.data)
+        # hadamard_in_channels: weight part only (hardmard_transform in float64, then the cast)
+        rhs, lhs, k = HadamardMatrix.get(n, scale=True, dtype=torch.float64)
+        arrays[f"{tag}|hadamard_in"] = _np(hardmard_transform(w.to(torch.float64), rhs, lhs, k, scaled=True).to(w.dtype))
+        # the transform in the tensor's own dtype, unscaled matrices (activation-side use)
+        rhs_u, lhs_u, k = HadamardMatrix.get(n, scale=False, dtype=torch.float64)
+        arrays[f"{tag}|hadamard_unscaled_f64"] = hardmard_transform(w.to(torch.float64), rhs_u, lhs_u, k).numpy()
+        meta[tag] = dict(rows=rows, n=n, dtype=dt, k=k, seed_random=1000 + n)
+    # output-channel rotation per head, with bias
+    for tag, heads, hc, cols, dt in (("out_bf16", 4, 16, 72, "bf16"), ("out_f16", 3, 12, 40, "f16")):
+        w = (torch.randn(heads * hc, cols, generator=g) * 0.05).to(TORCH_DT[dt])
+        b = (torch.randn(heads * hc, generator=g) * 0.1).to(TORCH_DT[dt])
+        torch.manual_seed(500 + hc)
+        rot = rrot.get_rotation_matrix(hc, random=True)
+        pw, pb = nn.Parameter(w.clone(), requires_grad=False), nn.Parameter(b.clone(), requires_grad=False)
+        rrot.rotate_out_channels(pw, rotation=rot, bias=pb)
+        arrays[f"{tag}|w"], arrays[f"{tag}|b"], arrays[f"{tag}|rotation"] = _np(w), _np(b), rot.numpy()
+        arrays[f"{tag}|w_out"], arrays[f"{tag}|b_out"] = _np(pw.data), _np(pb.data)
+        meta[tag] = dict(heads=heads, head_channels=hc, cols=cols, dtype=dt)
+    # norm folding
+    ln = nn.LayerNorm(64, bias=True)
+    ln.weight.data = torch.randn(64, generator=g).abs() + 0.5
+    ln.bias.data = torch.randn(64, generator=g) * 0.1
+    fc = nn.Linear(64, 32, bias=False).to(torch.bfloat16)
+    fc.weight.data = (torch.randn(32, 64, generator=g) * 0.05).to(torch.bfloat16)
+    arrays["norm|ln_w"], arrays["norm|ln_b"], arrays["norm|fc_w"] = _np(ln.weight.data), _np(ln.bias.data), _np(fc.weight.data)
+    rrot.transform_rms_norm_and_linear(ln, [fc])
+    arrays["norm|fc_w_out"], arrays["norm|fc_b_out"] = _np(fc.weight.data), _np(fc.bias.data)
+    np.savez_compressed(os.path.join(OUT, "rotate.npz"), **arrays)
+    with open(os.path.join(OUT, "rotate.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "tables", "gptq"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "tables", "gptq", "rotate"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
