@@ -1,6 +1,8 @@
 from .range import DynamicRangeCalibConfig, SkipBasedDynamicRangeCalibConfig
+from .smooth import SkipBasedSmoothCalibConfig, SmoothAttentionCalibConfig, SmoothCalibConfig, SmoothSpanMode
 from .search import (SearchBasedCalibConfig, SearchBasedCalibGranularity, SearchBasedCalibObjective,
                      SearchBasedCalibStrategy)
 
 __all__ = ["DynamicRangeCalibConfig", "SkipBasedDynamicRangeCalibConfig", "SearchBasedCalibConfig",
-           "SearchBasedCalibGranularity", "SearchBasedCalibObjective", "SearchBasedCalibStrategy"]
+           "SearchBasedCalibGranularity", "SearchBasedCalibObjective", "SearchBasedCalibStrategy",
+           "SkipBasedSmoothCalibConfig", "SmoothAttentionCalibConfig", "SmoothCalibConfig", "SmoothSpanMode"]

@@ -1,0 +1,432 @@
+"""Smooth quantization (reference: deepcompressor/calib/smooth.py:34-1109).
+
+Same call surface as the reference for the weight-centric path: ``smooth_linear_modules`` with a given scale or a
+``SmoothLinearCalibrator`` search (Manual / GridSearch over (alpha, beta) x span pairs, scored on the outputs of
+an evaluation module, Layer granularity).  What runs where:
+
+* per-channel spans of activations and weights        -> ``dcq_channel_metric``   (one pass each, HBM-bound)
+* ``W * s`` / ``W / s`` / ``x / s`` / ``x * s`` (+ cast) -> ``dcq_scale_channels``   (one pass, fused cast)
+* fake quantization of the scaled tensors             -> the ``Quantizer`` kernels
+* the evaluation module's forward                     -> torch on the GPU (the module belongs to the caller)
+
+Not implemented (raise): query/key smoothing search (``SmoothAttentionCalibrator``), ProductsError / ChannelGroup
+scoring, the low-rank-aware candidate processing.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import gc
+import typing as tp
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+from .._lib import check, lib, storage_of, stream_of
+from ..data.cache import TensorsCache
+from ..data.common import TensorType
+from ..quantizer.processor import ProcessHook, Quantizer
+from .config.search import SearchBasedCalibGranularity, SearchBasedCalibObjective
+from .config.smooth import SmoothCalibConfig, SmoothSpanMode
+from .metric import ChannelMetric
+
+__all__ = ["ActivationSmoother", "get_smooth_span", "get_smooth_scale", "scale_channels", "SmoothCalibrator",
+           "SmoothLinearCalibrator", "SmoothAttentionCalibrator", "smooth_upscale_param", "smooth_downscale_param",
+           "convert_smooth_upscale_to_downscale", "smooth_linear_modules", "smooth_attention"]
+
+
+def scale_channels(tensor: torch.Tensor, scale: torch.Tensor, channels_dim: int, *, divide: bool,
+                   out_dtype: torch.dtype | None = None) -> torch.Tensor:
+    """``(tensor.float() * scale).to(out_dtype)`` (or ``/``) with ``scale`` along ``channels_dim``; channels past
+    ``scale.numel()`` are only cast.  One fused pass on the GPU."""
+    out_dtype = out_dtype or tensor.dtype
+    src = tensor.contiguous()
+    dim = channels_dim % src.ndim
+    outer = int(torch.Size(src.shape[:dim]).numel())
+    channels = src.shape[dim]
+    inner = int(torch.Size(src.shape[dim + 1:]).numel())
+    scale = scale.to(device=src.device, dtype=torch.float32).contiguous().view(-1)
+    assert scale.numel() <= channels, "more scale entries than channels"
+    out = torch.empty(src.shape, dtype=out_dtype, device=src.device)
+    if src.numel():
+        check(lib().dcq_scale_channels(C.c_void_p(src.data_ptr()), storage_of(src.dtype), outer, channels, inner,
+                                       C.c_void_p(scale.data_ptr()), scale.numel(), int(divide),
+                                       C.c_void_p(out.data_ptr()), storage_of(out_dtype), stream_of(src.device)),
+              "dcq_scale_channels")
+    return out
+
+
+@dataclass
+class ActivationSmoother:
+    """Divides (or multiplies) a tensor by the smoothing scale along ``channels_dim`` (smooth.py:34-78)."""
+
+    smooth_scale: torch.Tensor
+    channels_dim: int
+    upscale: bool = False
+    develop_dtype: torch.dtype | None = None
+    input_packager: tp.Any = None
+    output_packager: tp.Any = None
+
+    def is_enabled(self) -> bool:
+        return self.smooth_scale is not None
+
+    def get_input_packager(self):
+        return self.input_packager
+
+    def get_output_packager(self):
+        return self.output_packager
+
+    def process(self, tensor: torch.Tensor) -> torch.Tensor:
+        if self.develop_dtype is None:
+            self.develop_dtype = tensor.dtype
+        if self.develop_dtype != torch.float32:
+            scale = self.smooth_scale.to(device=tensor.device, dtype=self.develop_dtype)
+            shape = [1] * tensor.ndim
+            shape[self.channels_dim] = -1
+            t = tensor.to(dtype=self.develop_dtype)
+            return (t.mul(scale.view(shape)) if self.upscale else t.div(scale.view(shape))).to(dtype=tensor.dtype)
+        return scale_channels(tensor, self.smooth_scale, self.channels_dim, divide=not self.upscale)
+
+    def as_hook(self, func=None, *, is_output: bool = False) -> ProcessHook:
+        return ProcessHook(self, func, is_output=is_output)
+
+
+@torch.inference_mode()
+def get_smooth_span(tensors: tp.Sequence[torch.Tensor], /, *, group_shape: tp.Sequence[int], span_mode: SmoothSpanMode,
+                    device: torch.device | str | None = None, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Per-channel span of tensors whose dimension 1 is the channel (smooth.py:81-113)."""
+    fn = {SmoothSpanMode.AbsMax: ChannelMetric.abs_max, SmoothSpanMode.RootMeanSquare: ChannelMetric.root_mean_square}
+    return fn[span_mode](tensors, tensors[0].shape[1], group_shape, device=device, dtype=dtype)
+
+
+@torch.inference_mode()
+def get_smooth_scale(*, alpha_base: torch.Tensor, beta_base: torch.Tensor, alpha: float, beta: float) -> torch.Tensor:
+    """alpha_base^alpha / beta_base^beta; zeros -> 1; any NaN / Inf -> all ones (smooth.py:116-146).
+    The powers are evaluated in float64 and rounded to the span dtype (within one unit in the last place of the
+    reference's float32 ``pow``)."""
+    assert 0 <= alpha <= 1 and 0 <= beta <= 1, "The smooth factors should be in [0, 1]."
+    power = lambda base, e: base.to(torch.float64).pow(e).to(base.dtype)  # noqa: E731
+    if alpha > 0:
+        smooth_scale = power(alpha_base, alpha)
+        if beta > 0:
+            smooth_scale = smooth_scale.div_(power(beta_base, beta))
+    else:
+        smooth_scale = power(beta_base, -beta)
+    smooth_scale[smooth_scale == 0] = 1
+    if smooth_scale.isnan().any() or smooth_scale.isinf().any():
+        smooth_scale = smooth_scale.fill_(1)
+    return smooth_scale
+
+
+def _head_reduce(span: torch.Tensor, unique_heads: int, repeats: int, use_max: bool) -> torch.Tensor:
+    """Grouped-query attention: heads that share a key/value head share one span (smooth.py:315-323, 340-343)."""
+    span = span.view(unique_heads, repeats, -1)
+    span = span.amax(dim=1, keepdim=True) if use_max else span.mean(dim=1, keepdim=True)
+    return span.expand(unique_heads, repeats, -1).reshape(-1)
+
+
+class SmoothCalibrator:
+    """Search over smoothing scales for x-w products (``tensor_type`` Weights).  Ask / tell structure, candidate
+    order and tie rule follow the reference (smooth.py:149-714, search.py:63-837)."""
+
+    def __init__(self, tensor_type: TensorType, config: SmoothCalibConfig, w_quantizer: Quantizer | None,
+                 x_quantizer: Quantizer | None, y_quantizer: Quantizer | None, num_heads: int = 1,
+                 num_head_repeats: int = 1, with_rope: bool = False, develop_dtype: torch.dtype = torch.float32) -> None:
+        assert tensor_type in (TensorType.Weights, TensorType.Outputs)
+        self.tensor_type, self.config, self.develop_dtype = tensor_type, config, develop_dtype
+        self.objective, self.granularity = config.objective, config.granularity
+        self.w_quantizer, self.x_quantizer, self.y_quantizer = w_quantizer, x_quantizer, y_quantizer
+        enabled = lambda q: q is not None and q.is_enabled()  # noqa: E731
+        self.needs_w_quant, self.needs_x_quant, self.needs_y_quant = map(enabled, (w_quantizer, x_quantizer, y_quantizer))
+        self.needs_x_quant_for_wgts = config.allow_a_quant and self.needs_x_quant
+        self.needs_w_quant_for_wgts = config.allow_b_quant and self.needs_w_quant
+        self.num_heads, self.num_head_repeats = num_heads, num_head_repeats
+        self.with_rope = tensor_type != TensorType.Weights and with_rope
+
+        def largest(q, needed):
+            return list(q.config.largest_group_shape) if needed else [1, None, -1]
+
+        w_gs, x_gs, y_gs = largest(w_quantizer, self.needs_w_quant), largest(x_quantizer, self.needs_x_quant), \
+            largest(y_quantizer, self.needs_y_quant)
+        w_gs[1] = x_gs[1] if w_gs[1] is None else w_gs[1]
+        x_gs[1] = (w_gs[1] if tensor_type == TensorType.Weights else y_gs[1]) if x_gs[1] is None else x_gs[1]
+        y_gs[1] = x_gs[1] if y_gs[1] is None else y_gs[1]
+        self.w_group_shape, self.x_group_shape, self.y_group_shape = w_gs, x_gs, y_gs
+        self.alpha_beta_pairs = config.get_alpha_beta_pairs()
+        self.num_iters = 1
+
+    # ---- candidates
+    @property
+    def population_size(self) -> int:
+        return len(self.alpha_beta_pairs) * len(self.config.spans)
+
+    def is_done(self) -> bool:
+        return self.iter >= self.num_iters
+
+    def reset(self, *, x_wgts: list[torch.Tensor], x_acts: TensorsCache, **kwargs) -> None:
+        self.iter = self.candidate_id = 0
+        self._state_dict: list[tuple[nn.Parameter, torch.Tensor]] = []
+        self._hooks: list = []
+        self.num_in_channels = x_wgts[0].shape[1]
+        device = x_wgts[0].device
+        grouped = self.num_heads > 1 and self.num_head_repeats > 1
+        self.num_unique_heads = self.num_heads // self.num_head_repeats if grouped else 0
+        assert x_acts.num_tensors == 1, f"Only one input is allowed, got {x_acts.num_tensors}"
+        x_tensors = x_acts.front().get_standardized_data(reshape=False)
+        assert all(x.shape[1] == self.num_in_channels for x in x_tensors)
+        assert all(w.shape[1] == self.num_in_channels for w in x_wgts)
+
+        def spans_of(tensors, group_shape, modes):
+            out = {}
+            for mode in modes:
+                span = get_smooth_span(tensors, group_shape=group_shape, span_mode=mode, device=device,
+                                       dtype=self.develop_dtype)
+                if self.num_unique_heads > 0:
+                    span = _head_reduce(span, self.num_unique_heads, self.num_head_repeats, "Max" in mode.name)
+                out[mode] = span
+            return out
+
+        x_spans = spans_of(x_tensors, self.x_group_shape, self.config.a_spans)
+        w_spans = spans_of([w.data for w in x_wgts], self.w_group_shape, self.config.b_spans)
+        self.span_pairs = [(x_spans[a], w_spans[b]) for a, b in self.config.spans]
+        self.best_error: list[torch.Tensor] | None = None
+        self.best_scale: torch.Tensor | None = None
+        self.error_history: list[list[torch.Tensor]] = []  # every candidate's errors, in candidate order
+
+    def get_best(self) -> torch.Tensor:
+        return self.best_scale
+
+    def ask(self) -> torch.Tensor:
+        alpha, beta = self.alpha_beta_pairs[self.candidate_id % len(self.alpha_beta_pairs)]
+        a_span, b_span = self.span_pairs[self.candidate_id // len(self.alpha_beta_pairs)]
+        if alpha == 0 and beta == 0:
+            self.candidate = torch.ones_like(a_span, dtype=self.develop_dtype)
+        else:
+            self.candidate = get_smooth_scale(alpha_base=a_span, beta_base=b_span, alpha=alpha, beta=beta)
+        return self.candidate
+
+    def tell(self, error: list[torch.Tensor]) -> None:
+        numel = error[0].numel()
+        assert all(e.numel() == numel for e in error)
+        if numel != 1:
+            raise NotImplementedError("channel-group wise smoothing errors are not implemented")
+        self.error_history.append(error)
+        # Layer granularity: a candidate replaces the best when it is not worse on every error (ties move on)
+        if self.best_error is None or all(bool(e <= b) for b, e in zip(self.best_error, error, strict=True)):
+            self.best_error, self.best_scale = error, self.candidate
+        self.candidate_id += 1
+        if self.candidate_id >= self.population_size:
+            self.iter += 1
+            self.candidate_id = 0
+
+    # ---- candidate processing
+    def _process_x_in_xw(self, x: torch.Tensor, channels_dim=None) -> torch.Tensor:
+        """x -> Q(x / s) * s in the develop dtype, back in x's dtype (smooth.py:504-517)."""
+        if not self.needs_x_quant_for_wgts:
+            return x
+        channels_dim = self.x_quantizer.channels_dim if channels_dim is None else channels_dim
+        dtype = x.dtype
+        xs = scale_channels(x, self.candidate, channels_dim, divide=True, out_dtype=self.develop_dtype)
+        xq = self.x_quantizer.quantize(xs, channels_dim=channels_dim, default_dtype=dtype,
+                                       develop_dtype=self.develop_dtype).data
+        return scale_channels(xq, self.candidate, channels_dim, divide=False, out_dtype=dtype).view(x.shape)
+
+    def _process_w_in_xw(self, w: torch.Tensor) -> torch.Tensor:
+        """w -> Q(w * s) / s (smooth.py:519-530)."""
+        if not self.needs_w_quant_for_wgts:
+            return w
+        dtype = w.dtype
+        channels_dim = 1 if self.w_quantizer.channels_dim is None else self.w_quantizer.channels_dim
+        ws = scale_channels(w, self.candidate, channels_dim, divide=False, out_dtype=self.develop_dtype)
+        wq = self.w_quantizer.quantize(ws, kernel=None, default_dtype=dtype, develop_dtype=self.develop_dtype).data
+        return scale_channels(wq, self.candidate, channels_dim, divide=True, out_dtype=dtype)
+
+    def _process_wgts_centric_mod(self, wgts: list[nn.Parameter], mods: list[nn.Module]) -> None:
+        if self.needs_w_quant_for_wgts and self.config.allow_low_rank and self.w_quantizer.is_enabled_low_rank():
+            raise NotImplementedError("low-rank-aware smoothing candidates are not implemented")
+        if self.needs_w_quant_for_wgts:
+            for w in wgts:
+                self._state_dict.append((w, w.data))
+                w.data = self._process_w_in_xw(w.data)
+        if self.needs_x_quant_for_wgts:
+            self._hooks.append(self.x_quantizer.as_hook(func=self._process_x_in_xw, is_output=False).register(mods))
+
+    def _recover_mod(self) -> None:
+        for p, w in self._state_dict:
+            p.data = w
+        self._state_dict.clear()
+        for hook in self._hooks:
+            hook.remove()
+        self._hooks.clear()
+
+    # ---- search
+    def _parse_inputs(self, ipts: TensorsCache | None) -> TensorsCache | None:
+        if ipts is None:
+            return None
+        return TensorsCache({key: ipt.repartition(max_batch_size=self.config.sample_batch_size,
+                                                  max_size=self.config.sample_size, standardize=False, reshape=True)
+                             for key, ipt in ipts.items()})
+
+    @torch.inference_mode()
+    def calibrate(self, x_wgts: list[nn.Parameter], x_acts: TensorsCache | None = None,
+                  x_mods: list[nn.Module] | None = None, eval_inputs: TensorsCache | None = None,
+                  eval_module: nn.Module | None = None, eval_kwargs: dict[str, tp.Any] | None = None,
+                  orig_x_wgts: list[tuple[nn.Parameter, torch.Tensor]] | None = None,
+                  orig_eval_inputs: TensorsCache | None = None, **kwargs) -> torch.Tensor:
+        if self.tensor_type != TensorType.Weights:
+            raise NotImplementedError("only the weight-centric (x-w) smoothing search is implemented")
+        assert all(isinstance(w, nn.Parameter) for w in x_wgts), "wgts should be a list of nn.Parameter"
+        objective, granularity = self.config.objective, self.config.granularity
+        if objective == SearchBasedCalibObjective.OutputsError and not (
+                isinstance(eval_module, (nn.Linear, nn.Conv2d)) and granularity != SearchBasedCalibGranularity.Layer):
+            granularity = SearchBasedCalibGranularity.Layer
+        else:
+            raise NotImplementedError(f"smoothing search with {objective.name} / {granularity.name} is not implemented")
+        assert eval_inputs is not None, "eval_inputs should not be None when objective is OutputsError"
+        assert eval_module is not None, "eval_module should not be None when OutputsError"
+        x_acts = x_acts or eval_inputs
+        eval_kwargs = eval_kwargs or {}
+        eval_inputs, orig_eval_inputs = self._parse_inputs(eval_inputs), self._parse_inputs(orig_eval_inputs)
+        self.reset(x_wgts=x_wgts, x_acts=x_acts)
+
+        def forward(cache: TensorsCache, index: int) -> torch.Tensor:
+            ipt = cache.extract(index, eval_kwargs)
+            y = eval_module(*ipt.args, **ipt.kwargs)
+            y = y[0] if not isinstance(y, torch.Tensor) else y
+            assert isinstance(y, torch.Tensor), "eval_mod should return a tensor"
+            return y
+
+        # the outputs to match: original weights (if given) on the original inputs (search.py:746-765)
+        saved = []
+        if orig_x_wgts is not None:
+            saved = [(p, p.data) for p, _ in orig_x_wgts]
+            for p, w in orig_x_wgts:
+                p.data = w.to(device=p.data.device)
+        ref_inputs = orig_eval_inputs or eval_inputs
+        num_batches = len(ref_inputs.front().data)
+        orig_opts = [forward(ref_inputs, i) for i in range(num_batches)]
+        for p, w in saved:
+            p.data = w
+        while not self.is_done():
+            self.ask()
+            self._process_wgts_centric_mod(wgts=x_wgts, mods=x_mods)
+            total = None
+            for i in range(len(eval_inputs.front().data)):
+                y = (forward(eval_inputs, i) - orig_opts[i].to(x_wgts[0].device)).to(self.develop_dtype)
+                y = y.pow_(self.config.degree).sum().view(-1)
+                total = y if total is None else total.add_(y)
+            self._recover_mod()
+            self.tell([total])
+        return self.get_best()
+
+
+class SmoothLinearCalibrator(SmoothCalibrator):
+    """Smoothing search for linear modules fed by the same activation (smooth.py:717-754)."""
+
+    def __init__(self, config: SmoothCalibConfig, weight_quantizer: Quantizer | None, input_quantizer: Quantizer | None,
+                 num_heads: int = 1, num_head_repeats: int = 1, develop_dtype: torch.dtype = torch.float32) -> None:
+        super().__init__(tensor_type=TensorType.Weights, config=config, w_quantizer=weight_quantizer,
+                         x_quantizer=input_quantizer, y_quantizer=None, num_heads=num_heads,
+                         num_head_repeats=num_head_repeats, develop_dtype=develop_dtype)
+
+
+class SmoothAttentionCalibrator(SmoothCalibrator):
+    """Query / key smoothing (smooth.py:757-849): constructible for configuration parity; the search raises."""
+
+    def __init__(self, config: SmoothCalibConfig, query_quantizer: Quantizer | None, key_quantizer: Quantizer | None,
+                 num_heads: int = 1, num_head_repeats: int = 1, with_rope: bool = True,
+                 develop_dtype: torch.dtype = torch.float32) -> None:
+        super().__init__(tensor_type=TensorType.Outputs, config=config, w_quantizer=None, x_quantizer=query_quantizer,
+                         y_quantizer=key_quantizer, num_heads=num_heads, num_head_repeats=num_head_repeats,
+                         with_rope=with_rope, develop_dtype=develop_dtype)
+
+
+def _check_finite(param: nn.Parameter) -> None:
+    assert not param.data.isnan().any(), "NaN found in param when smoothing"
+    assert not param.data.isinf().any(), "Inf found in param when smoothing"
+
+
+def smooth_upscale_param(param: nn.Parameter, scale: torch.Tensor, channels_dim: int = 1) -> None:
+    """param <- (param.to(scale.dtype) * scale).to(param.dtype) along ``channels_dim`` (smooth.py:852-869)."""
+    if scale.dtype != torch.float32:
+        shape = [1] * param.ndim
+        shape[channels_dim] = -1
+        param.data = param.data.to(dtype=scale.dtype).mul_(scale.to(param.device).view(shape)).to(dtype=param.dtype)
+    else:
+        param.data = scale_channels(param.data, scale, channels_dim, divide=False)
+    _check_finite(param)
+
+
+def smooth_downscale_param(param: nn.Parameter, scale: torch.Tensor, channels_dim: int = 0) -> None:
+    """The first ``scale.numel()`` channels of param are divided by scale (smooth.py:872-891)."""
+    if scale.dtype != torch.float32:
+        shape = [1] * param.ndim
+        shape[channels_dim] = -1
+        data = param.data.to(dtype=scale.dtype)
+        data.narrow(channels_dim, 0, scale.numel()).div_(scale.to(param.device).view(shape))
+        param.data = data.to(dtype=param.dtype)
+    else:
+        param.data = scale_channels(param.data, scale, channels_dim, divide=True)
+    _check_finite(param)
+
+
+def convert_smooth_upscale_to_downscale(scale: torch.Tensor, num_heads: int = 1, num_head_repeats: int = 1) -> torch.Tensor:
+    """With grouped-query attention the producer has one head per group of repeated heads (smooth.py:894-916)."""
+    if num_heads > 1 and num_head_repeats > 1:
+        head_channels = scale.numel() // num_heads
+        return scale.view(num_heads // num_head_repeats, num_head_repeats, head_channels)[:, 0, :].reshape(-1)
+    return scale
+
+
+@torch.inference_mode()
+def smooth_linear_modules(prevs: nn.Module | tp.Sequence[nn.Module] | None, modules: tp.Sequence[nn.Linear] | nn.Linear,
+                          *, scale: torch.Tensor | None, config: SmoothCalibConfig | None = None,
+                          weight_quantizer: Quantizer | None = None, input_quantizer: Quantizer | None = None,
+                          weights: list[nn.Parameter] | None = None, inputs: TensorsCache | None = None,
+                          eval_inputs: TensorsCache | None = None, eval_module: nn.Module = None,
+                          eval_kwargs: dict[str, tp.Any] = None, num_heads: int = 1, num_head_repeats: int = 1,
+                          splits: list[int] | None = None, extra_modules: list[nn.Linear] | None = None,
+                          develop_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Find (if ``scale`` is None) and apply the smoothing scale between ``prevs`` and ``modules``: the modules'
+    input channels are multiplied, the producers' output channels divided.  Returns the scale on the CPU
+    (smooth.py:919-1015)."""
+    modules = list(modules) if isinstance(modules, (list, tuple)) else [modules]
+    extra_modules = [] if extra_modules is None else list(extra_modules)
+    if scale is None:
+        assert inputs is not None or eval_inputs is not None, "inputs or eval_inputs must be provided"
+        scale = SmoothLinearCalibrator(config=config, weight_quantizer=weight_quantizer, input_quantizer=input_quantizer,
+                                       num_heads=num_heads, num_head_repeats=num_head_repeats,
+                                       develop_dtype=develop_dtype).calibrate(
+            x_wgts=[m.weight for m in modules] if weights is None else weights, x_acts=inputs, x_mods=modules,
+            eval_inputs=eval_inputs, eval_module=eval_module, eval_kwargs=eval_kwargs, splits=splits)
+        gc.collect()
+        torch.cuda.empty_cache()
+    upscale = scale
+    for module in modules + extra_modules:
+        upscale = upscale.to(device=module.weight.device)
+        smooth_upscale_param(module.weight, upscale, channels_dim=1)
+    if prevs is not None:
+        downscale = convert_smooth_upscale_to_downscale(upscale, num_heads=num_heads, num_head_repeats=num_head_repeats)
+        for module in [prevs] if isinstance(prevs, nn.Module) else prevs:
+            if module is None:
+                continue
+            downscale = downscale.to(device=module.weight.device)
+            smooth_downscale_param(module.weight, downscale, channels_dim=0)
+            if getattr(module, "bias", None) is not None:
+                smooth_downscale_param(module.bias, downscale, channels_dim=0)
+    return scale.to(device="cpu")
+
+
+@torch.inference_mode()
+def smooth_attention(*, q_proj: nn.Linear, k_proj: nn.Linear, scale: torch.Tensor | None, num_heads: int = 1,
+                     num_head_repeats: int = 1, **kwargs) -> torch.Tensor:
+    """Apply a given query / key smoothing scale: q_proj rows are multiplied, k_proj rows divided
+    (smooth.py:1018-1109).  Searching for the scale is not implemented."""
+    if scale is None:
+        raise NotImplementedError("the query / key smoothing search is not implemented; pass `scale`")
+    upscale = scale.to(device=q_proj.weight.device)
+    smooth_upscale_param(q_proj.weight, upscale, channels_dim=0)
+    downscale = convert_smooth_upscale_to_downscale(upscale, num_heads=num_heads, num_head_repeats=num_head_repeats)
+    smooth_downscale_param(k_proj.weight, downscale, channels_dim=0)
+    return scale.to(device="cpu")

@@ -113,7 +113,7 @@ __device__ __forceinline__ void load_to_lds_16(const void* gsrc, void* lds_wave_
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                :
                : "v"(gsrc), "s"(lds_addr)
-               : "memory", "m0");
+               : "memory");  // M0 is a reserved register: the compiler keeps nothing in it across statements
 }
 
 __device__ __forceinline__ void wait_direct_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0) only

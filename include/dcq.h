@@ -271,6 +271,27 @@ int dcq_gemm_f64(const void* A, int32_t a_storage, int64_t lda, int32_t a_kmajor
                  int32_t b_storage, int64_t ldb, int64_t b_batch_stride, void* C, int32_t c_storage, int64_t ldc,
                  int64_t c_batch_stride, int64_t M, int64_t N, int64_t K, int64_t batch, dcq_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Smooth quantization (deepcompressor/calib/metric.py:31-86, calib/smooth.py:56-78, 852-891).
+ *
+ * dcq_channel_metric: x viewed as [N][C][inner] (float32 / float16 / bfloat16); per channel c, over all n and i:
+ *   mode 0: max |x|          -> out_max[C] float32  (ChannelMetric._abs_max; caller zero-fills out_max; exact)
+ *   mode 1: sum |x|          -> out_sum[C] float64  (ChannelMetric._abs_sum; caller zero-fills out_sum)
+ *   mode 2: sum x^2          -> out_sum[C] float64  (ChannelMetric._square_sum)
+ * Terms are formed in float32 as the reference does; workgroup partial sums (float32) are combined in float64.
+ * Calls accumulate into the outputs, so a list of tensors is reduced by calling once per tensor.
+ *
+ * dcq_scale_channels: y[o][c][i] = storage(float32(x[o][c][i]) * scale[c])  (or / scale[c] when divide != 0) for
+ * c < scaled_channels, a plain cast for the other channels: `param.to(float32).mul_(scale).to(dtype)`
+ * (smooth_upscale_param), `narrow(dim, 0, scale.numel()).div_(scale)` (smooth_downscale_param) and
+ * ActivationSmoother.process.  x and y may be the same buffer when the storage types match.
+ * ------------------------------------------------------------------------------------------- */
+int dcq_channel_metric(const void* x, int32_t storage, int64_t N, int64_t C, int64_t inner, int32_t mode, float* out_max,
+                       double* out_sum, dcq_stream_t stream);
+
+int dcq_scale_channels(const void* x, int32_t storage, int64_t outer, int64_t C, int64_t inner, const float* scale,
+                       int64_t scaled_channels, int32_t divide, void* y, int32_t out_storage, dcq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -335,11 +335,137 @@ def gen_rotate(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+def gen_smooth(ref) -> None:
+    """Spans, candidate lists, scales, applied scales and a small search from the reference's smooth module
+    (deepcompressor/calib/smooth.py, calib/metric.py, calib/config/smooth.py)."""
+    import torch.nn as nn
+    from deepcompressor.calib import smooth as rs
+    from deepcompressor.calib.config import SearchBasedCalibGranularity, SearchBasedCalibObjective, SearchBasedCalibStrategy
+    from deepcompressor.calib.config.smooth import SmoothCalibConfig, SmoothSpanMode
+    from deepcompressor.calib.metric import ChannelMetric
+    from deepcompressor.data.cache import TensorCache, TensorsCache
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+
+    arrays, meta = {}, {"pairs": {}, "dirnames": {}}
+    # candidate lists
+    for alpha in (0.5, 0, -1, -2, -3):
+        for beta in (0.5, 0, -1, -2, -3):
+            cfg = SmoothCalibConfig(spans=[(SmoothSpanMode.AbsMax, SmoothSpanMode.AbsMax)], alpha=alpha, beta=beta,
+                                    num_grids=5, strategy=SearchBasedCalibStrategy.GridSearch)
+            meta["pairs"][f"{alpha}|{beta}"] = [list(p) for p in cfg.get_alpha_beta_pairs()]
+            meta["dirnames"][f"{alpha}|{beta}"] = cfg.generate_dirnames(prefix="smooth")
+    for alpha, beta in ((0.3, 0.7), (0.5, -1), (-1, 0.25), (0.5, 0)):
+        cfg = SmoothCalibConfig(spans=[("AbsMax", "RootMeanSquare")], alpha=alpha, beta=beta)
+        meta["pairs"][f"manual|{alpha}|{beta}"] = [list(p) for p in cfg.get_alpha_beta_pairs()]
+        meta["dirnames"][f"manual|{alpha}|{beta}"] = cfg.generate_dirnames()
+    # spans
+    g = torch.Generator().manual_seed(99)
+    for dt in ("bf16", "f16"):
+        xs = [(torch.randn(n, 96, generator=g) * torch.exp(torch.randn(96, generator=g))).to(TORCH_DT[dt]) for n in (40, 24, 8)]
+        xs[0][:, 5] = 0
+        ws = [(torch.randn(r, 96, generator=g) * 0.05).to(TORCH_DT[dt]) for r in (64, 32)]
+        conv = (torch.randn(6, 96, 3, 3, generator=g) * 0.1).to(TORCH_DT[dt])
+        for i, x in enumerate(xs):
+            arrays[f"span|{dt}|x{i}"] = _np(x)
+        for i, w in enumerate(ws):
+            arrays[f"span|{dt}|w{i}"] = _np(w)
+        arrays[f"span|{dt}|conv"] = _np(conv)
+        for mode in ("abs_max", "abs_mean", "root_mean_square"):
+            fn = getattr(ChannelMetric, mode)
+            arrays[f"span|{dt}|x|{mode}"] = fn(xs, 96, [1, -1], dtype=torch.float32).numpy()
+            arrays[f"span|{dt}|w|{mode}"] = fn(ws, 96, [1, -1], dtype=torch.float32).numpy()
+            arrays[f"span|{dt}|conv|{mode}"] = fn(conv, 96, [1, -1], dtype=torch.float32).numpy()
+        a_span = arrays[f"span|{dt}|x|abs_max"]
+        b_span = arrays[f"span|{dt}|w|abs_max"]
+        for alpha, beta in ((0.5, 0.5), (0.3, 0.7), (0.85, 0), (0, 0.4), (1.0, 1.0)):
+            s = rs.get_smooth_scale(alpha_base=torch.from_numpy(a_span.copy()), beta_base=torch.from_numpy(b_span.copy()),
+                                    alpha=alpha, beta=beta)
+            arrays[f"scale|{dt}|{alpha}|{beta}"] = s.numpy()
+    # applying a scale
+    for dt in ("bf16", "f16"):
+        prev = nn.Linear(48, 64, bias=True).to(TORCH_DT[dt])
+        mods = [nn.Linear(64, 40, bias=False).to(TORCH_DT[dt]), nn.Linear(64, 24, bias=False).to(TORCH_DT[dt])]
+        for m in [prev] + mods:
+            m.weight.data = (torch.randn(m.weight.shape, generator=g) * 0.07).to(TORCH_DT[dt])
+        prev.bias.data = (torch.randn(64, generator=g) * 0.1).to(TORCH_DT[dt])
+        scale = torch.exp(torch.randn(64, generator=g) * 0.7)
+        arrays[f"apply|{dt}|scale"] = scale.numpy()
+        arrays[f"apply|{dt}|prev_w"], arrays[f"apply|{dt}|prev_b"] = _np(prev.weight.data), _np(prev.bias.data)
+        for i, m in enumerate(mods):
+            arrays[f"apply|{dt}|w{i}"] = _np(m.weight.data)
+        rs.smooth_linear_modules(prev, mods, scale=scale.clone())
+        arrays[f"apply|{dt}|prev_w_out"], arrays[f"apply|{dt}|prev_b_out"] = _np(prev.weight.data), _np(prev.bias.data)
+        for i, m in enumerate(mods):
+            arrays[f"apply|{dt}|w{i}_out"] = _np(m.weight.data)
+        # grouped-query layout: 4 heads x 16 channels on the consumer, 2 key/value heads on the producer
+        prev2 = nn.Linear(48, 32, bias=False).to(TORCH_DT[dt])
+        prev2.weight.data = (torch.randn(32, 48, generator=g) * 0.07).to(TORCH_DT[dt])
+        mod2 = nn.Linear(64, 40, bias=False).to(TORCH_DT[dt])
+        mod2.weight.data = (torch.randn(40, 64, generator=g) * 0.07).to(TORCH_DT[dt])
+        s_half = torch.exp(torch.randn(2, 1, 16, generator=g) * 0.5).expand(2, 2, 16).reshape(-1).contiguous()
+        arrays[f"apply_gqa|{dt}|scale"], arrays[f"apply_gqa|{dt}|prev_w"] = s_half.numpy(), _np(prev2.weight.data)
+        arrays[f"apply_gqa|{dt}|w"] = _np(mod2.weight.data)
+        rs.smooth_linear_modules(prev2, mod2, scale=s_half.clone(), num_heads=4, num_head_repeats=2)
+        arrays[f"apply_gqa|{dt}|prev_w_out"], arrays[f"apply_gqa|{dt}|w_out"] = _np(prev2.weight.data), _np(mod2.weight.data)
+
+    # a small search: two float32 linears fed by the same activation, sint4 weights (group 16), sint8 per-token inputs
+    class Pair(nn.Module):
+        def __init__(self, a, b):
+            super().__init__()
+            self.a, self.b = a, b
+
+        def forward(self, x):
+            return torch.cat([self.a(x), self.b(x)], dim=-1)
+
+    from deepcompressor.data.dtype import QuantDataType
+    from deepcompressor.quantizer import Quantizer as RefQuantizer
+    from deepcompressor.quantizer.config.base import QuantizerConfig as RefQuantizerConfig
+
+    for tag, strategy, alpha, beta in (("grid", SearchBasedCalibStrategy.GridSearch, 0.5, -2),
+                                       ("manual", SearchBasedCalibStrategy.Manual, 0.3, 0.7)):
+        a, b = nn.Linear(64, 40, bias=False), nn.Linear(64, 24, bias=False)
+        a.weight.data = torch.randn(40, 64, generator=g) * 0.08
+        b.weight.data = torch.randn(24, 64, generator=g) * 0.08
+        gains = torch.exp(torch.randn(64, generator=g) * 1.2)
+        xs = [torch.randn(2, 12, 64, generator=g) * gains for _ in range(3)]
+        arrays[f"search|{tag}|wa"], arrays[f"search|{tag}|wb"] = a.weight.data.numpy().copy(), b.weight.data.numpy().copy()
+        for i, x in enumerate(xs):
+            arrays[f"search|{tag}|x{i}"] = x.numpy().copy()
+        wq = RefQuantizer(RefQuantizerConfig(dtype=QuantDataType.from_str("sint4"), zero_point=None,
+                                             group_shapes=((1, 16),), scale_dtypes=(torch.float16,)), key="w")
+        xq = RefQuantizer(RefQuantizerConfig(dtype=QuantDataType.from_str("sint8"), zero_point=None,
+                                             group_shapes=((1, -1),), scale_dtypes=(torch.float16,)), channels_dim=-1,
+                          key="x")
+        cfg = SmoothCalibConfig(spans=[(SmoothSpanMode.AbsMax, SmoothSpanMode.AbsMax)], alpha=alpha, beta=beta,
+                                num_grids=20, strategy=strategy, objective=SearchBasedCalibObjective.OutputsError,
+                                granularity=SearchBasedCalibGranularity.Layer, degree=2)
+        cache = TensorsCache(TensorCache(list(xs), channels_dim=-1, reshape=LinearReshapeFn(), num_cached=3, num_total=3,
+                                         num_samples=6, orig_device=torch.device("cpu")))
+        calib = rs.SmoothLinearCalibrator(cfg, wq, xq)
+        errors = []
+        orig_tell = calib._tell
+
+        def spy(error, _orig=orig_tell, _errors=errors):
+            _errors.append(float(error[0]))
+            return _orig(error)
+
+        calib._tell = spy
+        best = calib.calibrate(x_wgts=[a.weight, b.weight], x_acts=cache, x_mods=[a, b], eval_inputs=cache,
+                               eval_module=Pair(a, b), eval_kwargs={})
+        arrays[f"search|{tag}|best_scale"] = best.numpy().copy()
+        arrays[f"search|{tag}|errors"] = np.array(errors, dtype=np.float64)
+        meta[f"search|{tag}"] = dict(alpha=alpha, beta=beta, strategy=strategy.name, num_candidates=len(errors),
+                                     best_index=int(np.argmin(errors)))
+    np.savez_compressed(os.path.join(OUT, "smooth.npz"), **arrays)
+    with open(os.path.join(OUT, "smooth.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "tables", "gptq", "rotate"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "tables", "gptq", "rotate", "smooth"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
