@@ -135,6 +135,53 @@ class Quantizer(QuantizerImpl):
             range_bound=self.range_bound if range_bound is MISSING else range_bound)
 
     # ---- checkpoint layout (wgts.pt / acts.pt entries) ---------------------------------------
+    def quantize_with_low_rank(self, tensors: torch.Tensor | tp.Sequence[torch.Tensor], /, *,
+                               return_with_dequant: bool = True, return_with_quant: bool = False, **qkwargs):
+        """Quantize weights together with their low-rank branch (reference: quantizer/processor.py:215-310).
+
+        One branch per tensor (single tensor or ``exclusive``) or one branch fitted on the row-wise concatenation
+        with the up-projection split back per tensor.  ``compensate``: quantize first, fit the branch to the
+        error; otherwise fit the branch to the weight and quantize the remainder.  Returns (QuantTensors, branches)
+        -- branches is None when the low-rank branch is disabled."""
+        from ..nn.patch.lowrank import LowRankBranch
+
+        tensors = [tensors] if isinstance(tensors, torch.Tensor) else list(tensors)
+        qkwargs = dict(return_with_dequant=return_with_dequant, return_with_quant=return_with_quant, **qkwargs)
+        if not self.is_enabled_low_rank():
+            return [self.quantize(t.data, **qkwargs) for t in tensors], None
+        rank, compensate = self.low_rank.rank, self.low_rank.compensate
+        if compensate:
+            qkwargs["return_with_dequant"] = True
+        qtensors, branches = [], []
+        if len(tensors) == 1 or self.low_rank.exclusive:
+            for t in tensors:
+                if compensate:
+                    qt = self.quantize(t.data, **qkwargs)
+                    lb = LowRankBranch(t.shape[1], t.shape[0], rank=rank, weight=t.data - qt.data)
+                else:
+                    lb = LowRankBranch(t.shape[1], t.shape[0], rank=rank, weight=t.data)
+                    qt = self.quantize(t.data - lb.get_effective_weight().view(t.data.shape), **qkwargs)
+                qtensors.append(qt)
+                branches.append(lb)
+            return qtensors, branches
+        stacked = torch.cat([t.data for t in tensors], dim=0)
+        if compensate:
+            qtensors = [self.quantize(t.data, **qkwargs) for t in tensors]
+            stacked = stacked - torch.cat([q.data for q in qtensors], dim=0)
+        shared = LowRankBranch(stacked.shape[1], stacked.shape[0], rank=rank, weight=stacked)
+        del stacked
+        start = 0
+        for t in tensors:
+            lb = LowRankBranch(t.shape[1], t.shape[0], rank=rank)
+            lb.a = shared.a
+            lb.b.to(dtype=t.dtype, device=t.device)
+            lb.b.weight.data.copy_(shared.b.weight[start:start + t.shape[0]])
+            start += t.shape[0]
+            if not compensate:
+                qtensors.append(self.quantize(t.data - lb.get_effective_weight(), **qkwargs))
+            branches.append(lb)
+        return qtensors, branches
+
     def state_dict(self, device: torch.device | str = "cpu") -> dict[str, tp.Any]:
         copy = lambda t: t.to(device).clone()  # noqa: E731
         if self.dynamic_range is None:

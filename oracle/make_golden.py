@@ -461,11 +461,94 @@ def gen_smooth(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+@torch.no_grad()
+def gen_lowrank(ref) -> None:
+    """Low-rank branches, joint quantization and the alternating calibration from the reference
+    (deepcompressor/nn/patch/lowrank.py, quantizer/processor.py:215-310, calib/lowrank.py)."""
+    import torch.nn as nn
+    from deepcompressor.calib.config import SearchBasedCalibObjective
+    from deepcompressor.calib.config.lowrank import QuantLowRankCalibConfig
+    from deepcompressor.calib.lowrank import QuantLowRankCalibrator
+    from deepcompressor.data.cache import TensorCache, TensorsCache
+    from deepcompressor.data.dtype import QuantDataType
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+    from deepcompressor.nn.patch.lowrank import LowRankBranch
+    from deepcompressor.quantizer import Quantizer as RefQuantizer
+    from deepcompressor.quantizer.config.base import QuantizerConfig as RefQuantizerConfig
+    from deepcompressor.quantizer.config.lowrank import QuantLowRankConfig
+
+    arrays, meta = {}, {"dirnames": {}}
+    g = torch.Generator().manual_seed(2024)
+
+    def lowrank_weight(rows, cols, rank_signal=6):
+        # a decaying spectrum so the leading singular subspace is well separated
+        u = torch.linalg.qr(torch.randn(rows, rows, generator=g))[0][:, :rank_signal]
+        v = torch.linalg.qr(torch.randn(cols, cols, generator=g))[0][:, :rank_signal]
+        sv = torch.tensor([3.0, 2.2, 1.6, 1.1, 0.8, 0.55])[:rank_signal]
+        return (u * sv) @ v.T * 0.2 + torch.randn(rows, cols, generator=g) * 0.02
+
+    for dt in ("f32", "bf16"):
+        w = lowrank_weight(48, 64).to(TORCH_DT[dt])
+        lb = LowRankBranch(64, 48, rank=4, weight=w)
+        arrays[f"branch|{dt}|w"] = _np(w)
+        arrays[f"branch|{dt}|effective"] = _np(lb.get_effective_weight())
+        arrays[f"branch|{dt}|singular"] = torch.linalg.svdvals(w.double()).numpy()
+        x = torch.randn(5, 64, generator=g).to(TORCH_DT[dt])
+        arrays[f"branch|{dt}|x"], arrays[f"branch|{dt}|y"] = _np(x), _np(lb(x))
+
+    def wq_with(low_rank):
+        return RefQuantizer(RefQuantizerConfig(dtype=QuantDataType.from_str("sint4"), zero_point=None,
+                                               group_shapes=((1, 16),), scale_dtypes=(torch.float16,)),
+                            key="w", low_rank=low_rank)
+
+    w1, w2 = lowrank_weight(40, 64), lowrank_weight(24, 64)
+    arrays["joint|w1"], arrays["joint|w2"] = w1.numpy().copy(), w2.numpy().copy()
+    for tag, kw in (("shared", dict(rank=4)), ("exclusive", dict(rank=4, exclusive=True)),
+                    ("compensate", dict(rank=4, compensate=True)), ("exclusive_compensate", dict(rank=4, exclusive=True, compensate=True))):
+        qts, lbs = wq_with(QuantLowRankConfig(**kw)).quantize_with_low_rank([w1.clone(), w2.clone()])
+        for i, (qt, lb) in enumerate(zip(qts, lbs)):
+            arrays[f"joint|{tag}|q{i}"] = _np(qt.data)
+            arrays[f"joint|{tag}|l{i}"] = _np(lb.get_effective_weight())
+    for kw in (dict(rank=8, num_iters=4, early_stop=True), dict(rank=16, exclusive=True), dict(rank=32, compensate=True),
+               dict(rank=32, compensate=True, num_iters=3)):
+        cfg = QuantLowRankCalibConfig(**kw)
+        meta["dirnames"][json.dumps(kw, sort_keys=True)] = cfg.generate_dirnames(prefix="lr")
+
+    # alternating calibration on one float32 linear
+    lin = nn.Linear(64, 40, bias=False)
+    lin.weight.data = lowrank_weight(40, 64)
+    xs = [torch.randn(2, 10, 64, generator=g) for _ in range(3)]
+    arrays["calib|w"] = lin.weight.data.numpy().copy()
+    for i, x in enumerate(xs):
+        arrays[f"calib|x{i}"] = x.numpy().copy()
+    xq = RefQuantizer(RefQuantizerConfig(dtype=QuantDataType.from_str("sint8"), zero_point=None, group_shapes=((1, -1),),
+                                         scale_dtypes=(torch.float16,)), channels_dim=-1, key="x")
+    cfg = QuantLowRankCalibConfig(rank=4, num_iters=5, early_stop=False, objective=SearchBasedCalibObjective.OutputsError)
+    cache = TensorsCache(TensorCache(list(xs), channels_dim=-1, reshape=LinearReshapeFn(), num_cached=3, num_total=3,
+                                     num_samples=6, orig_device=torch.device("cpu")))
+    calib = QuantLowRankCalibrator(cfg, wq_with(None), xq)
+    errors = []
+    orig_tell = calib._tell
+
+    def spy(error, _orig=orig_tell):
+        errors.append(float(error[0] if isinstance(error, (list, tuple)) else error))
+        return _orig(error)
+
+    calib._tell = spy
+    best = calib.calibrate(x_wgts=[lin.weight], x_mods=[lin], eval_inputs=cache, eval_module=lin, eval_kwargs={})
+    arrays["calib|errors"] = np.array(errors, dtype=np.float64)
+    arrays["calib|best_effective"] = _np(best.get_effective_weight())
+    meta["calib"] = dict(num_iters=5, rank=4, best_index=int(np.argmin(errors)))
+    np.savez_compressed(os.path.join(OUT, "lowrank.npz"), **arrays)
+    with open(os.path.join(OUT, "lowrank.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "tables", "gptq", "rotate", "smooth"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "tables", "gptq", "rotate", "smooth", "lowrank"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)

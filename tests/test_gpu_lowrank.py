@@ -1,0 +1,95 @@
+"""Low-rank branch, joint quantization and alternating calibration on the GPU against the reference's fixtures.
+
+The SVD is LAPACK-on-GPU there and LAPACK-on-CPU in the reference: singular vectors agree up to sign and to the last
+bits, so the bar is on products: b @ a within 1e-5 of the weight scale (float32) / one bfloat16 step, dequantized
+weights identical except <= 0.2 % of elements that sat within that noise of a rounding boundary, calibration errors
+within 5e-3 relative with the same iterate chosen.
+"""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from _product import to_device, to_np
+from conftest import load_golden
+
+from deepcompressor_amd.calib.config import QuantLowRankCalibConfig, SearchBasedCalibObjective
+from deepcompressor_amd.calib.lowrank import QuantLowRankCalibrator
+from deepcompressor_amd.data.cache import TensorCache, TensorsCache
+from deepcompressor_amd.data.dtype import QDType
+from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
+from deepcompressor_amd.nn.patch import LowRankBranch
+from deepcompressor_amd.quantizer import Quantizer, QuantizerConfig
+from deepcompressor_amd.quantizer.config.lowrank import QuantLowRankConfig
+
+pytestmark = pytest.mark.gpu
+G = load_golden("lowrank")
+
+
+def _wq(low_rank=None):
+    return Quantizer(QuantizerConfig(dtype=QDType.sint4, zero_point=None, group_shapes=((1, 16),), scale_dtypes=(torch.float16,)),
+                     key="w", low_rank=low_rank)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_branch_fixture(dt):
+    w = to_device(G[f"branch|{dt}|w"], dt)
+    lb = LowRankBranch(64, 48, rank=4, weight=w)
+    assert lb.a.weight.dtype == w.dtype and lb.a.weight.shape == (4, 64) and lb.b.weight.shape == (48, 4)
+    tol = 1e-5 if dt == "f32" else 2.0 ** -8
+    eff = to_np(lb.get_effective_weight())
+    assert np.abs(eff - G[f"branch|{dt}|effective"]).max() <= tol * np.abs(G[f"branch|{dt}|w"]).max()
+    y = to_np(lb(to_device(G[f"branch|{dt}|x"], dt)))
+    want = G[f"branch|{dt}|y"]
+    assert np.abs(y - want).max() <= (1e-5 if dt == "f32" else 2.0 ** -6) * np.abs(want).max()
+    # as a hook the branch adds its output to the module's
+    lin = nn.Linear(64, 48, bias=False, device="cuda", dtype=w.dtype)
+    x = to_device(G[f"branch|{dt}|x"], dt)
+    base = lin(x)
+    hook = lb.as_hook().register(lin)
+    assert torch.allclose(lin(x).float(), (base + lb(x)).float(), atol=1e-6)
+    hook.remove()
+    assert torch.equal(lin(x), base)
+
+
+@pytest.mark.parametrize("tag,kw", [("shared", dict(rank=4)), ("exclusive", dict(rank=4, exclusive=True)),
+                                    ("compensate", dict(rank=4, compensate=True)),
+                                    ("exclusive_compensate", dict(rank=4, exclusive=True, compensate=True))])
+def test_quantize_with_low_rank_fixture(tag, kw):
+    ws = [torch.from_numpy(G["joint|w1"]).cuda(), torch.from_numpy(G["joint|w2"]).cuda()]
+    qts, lbs = _wq(QuantLowRankConfig(**kw)).quantize_with_low_rank([w.clone() for w in ws])
+    assert len(qts) == len(lbs) == 2
+    if not kw.get("exclusive") and not kw.get("compensate"):
+        assert lbs[0].a is lbs[1].a, "weights sharing their input share the down-projection"
+    for i, (qt, lb) in enumerate(zip(qts, lbs)):
+        low = to_np(lb.get_effective_weight())
+        assert np.abs(low - G[f"joint|{tag}|l{i}"]).max() <= 1e-5 * np.abs(G[f"joint|w{i + 1}"]).max(), (tag, i)
+        q, want = to_np(qt.data), G[f"joint|{tag}|q{i}"]
+        assert (q != want).mean() <= 2e-3, (tag, i, (q != want).mean())
+    qts, lbs = _wq(None).quantize_with_low_rank(ws[0])
+    assert lbs is None and len(qts) == 1
+
+
+def test_calibration_fixture():
+    lin = nn.Linear(64, 40, bias=False, device="cuda")
+    lin.weight.data = torch.from_numpy(G["calib|w"]).cuda()
+    w0 = lin.weight.data.clone()
+    xs = [torch.from_numpy(G[f"calib|x{i}"]).cuda() for i in range(3)]
+    xq = Quantizer(QuantizerConfig(dtype=QDType.sint8, zero_point=None, group_shapes=((1, -1),), scale_dtypes=(torch.float16,)),
+                   channels_dim=-1, key="x")
+    cfg = QuantLowRankCalibConfig(rank=4, num_iters=5, early_stop=False, objective=SearchBasedCalibObjective.OutputsError)
+    cache = TensorsCache(TensorCache(xs, channels_dim=-1, reshape=LinearReshapeFn(), num_cached=3, num_total=3, num_samples=6,
+                                     orig_device=torch.device("cuda")))
+    calib = QuantLowRankCalibrator(cfg, _wq(None), xq)
+    best = calib.calibrate(x_wgts=[lin.weight], x_mods=[lin], eval_inputs=cache, eval_module=lin, eval_kwargs={})
+    assert torch.equal(lin.weight.data, w0) and len(lin._forward_hooks) == 0 and len(lin._forward_pre_hooks) == 0
+    errors, want = np.array(calib.error_history), G["calib|errors"]
+    assert np.all(np.abs(errors - want) <= 5e-3 * want), np.abs(errors / want - 1).max()
+    assert int(np.argmin(errors)) == G.meta["calib"]["best_index"]
+    assert np.abs(to_np(best.get_effective_weight()) - G["calib|best_effective"]).max() <= 2e-3 * np.abs(G["calib|w"]).max()
+    # early stop ends at the first iteration that does not improve
+    cfg2 = QuantLowRankCalibConfig(rank=4, num_iters=50, early_stop=True, objective=SearchBasedCalibObjective.OutputsError)
+    calib2 = QuantLowRankCalibrator(cfg2, _wq(None), xq)
+    calib2.calibrate(x_wgts=[lin.weight], x_mods=[lin], eval_inputs=cache, eval_module=lin, eval_kwargs={})
+    h = calib2.error_history
+    assert len(h) < 50 and h[-1] > min(h[:-1]) and all(h[i + 1] <= h[i] for i in range(len(h) - 2))
