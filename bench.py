@@ -98,6 +98,40 @@ def quantize_layer(weights, caches, objs, syrk_events=None):
     return out
 
 
+def stage_rates(device, weights, objs) -> dict:
+    """Achieved rates of the two HBM/VALU-bound stages on the largest linear (outside the timed steps):
+    the fused fake-quant pass against its 4.03 B/param of algorithmic traffic, and the 101-candidate range search."""
+    from deepcompressor_amd.calib import calibrate_dynamic_range
+    from deepcompressor_amd.data.common import TensorType
+    import torch.nn as nn
+
+    Quantizer, qcfg, rcfg, _ = objs
+    w = weights["gate_proj"]
+    q = Quantizer(qcfg, key="rate", develop_dtype=torch.float32)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    t_fq = timed(lambda: q.quantize(w), 20)
+    t_rs = timed(lambda: calibrate_dynamic_range(TensorType.Weights, rcfg, True, q, modules=[None], activations=None,
+                                                 weights=[nn.Parameter(w, requires_grad=False)]), 3)
+    n = w.numel()
+    fq_bytes = n * 4 + (n // 128) * 8  # bf16 read + bf16 write, float32 scale + zero per group
+    return {"fake_quant": {"shape": list(w.shape), "seconds": t_fq, "GBps": fq_bytes / t_fq / 1e9,
+                           "frac_of_8TBps": fq_bytes / t_fq / 8e12, "note": "Quantizer.quantize wall time per call "
+                           "(one fused kernel + host glue), algorithmic 4.06 B/param"},
+            "range_search": {"shape": list(w.shape), "candidates": 101, "seconds": t_rs, "Gparam_per_s": n / t_rs / 1e9,
+                             "Gcandidate_evals_per_s": n * 101 / t_rs / 1e9}}
+
+
 def cpu_baseline(tokens_sample: int = 8192):
     """The CPU oracle (numpy restatement of the reference) on a bounded sample: k_proj (1024 x 4096) with a
     reduced token count.  Returns the cpu_baseline object of the bench contract."""
@@ -190,6 +224,8 @@ def main() -> None:
                          "share_of_step": syrk_ms * 1e-3 / elapsed,
                          "executed_tflops": exec_flop / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0},
         }
+        if world == 1:
+            line["stages"] = stage_rates(device, weights, objs)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
