@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from deepcompressor_amd.parallel import all_reduce_sum, assign_by_cost, assign_round_robin, barrier_and_max
+from deepcompressor_amd.parallel import (all_reduce_sum, assign_by_cost, assign_round_robin, barrier_and_max,
+                                         map_rows_sharded, row_shard)
 
 
 def _free_port() -> int:
@@ -26,7 +27,15 @@ def _worker(rank: int, world: int, port: int, out):
         elapsed = barrier_and_max(1.0 + rank, world)
         # per-tensor statistics (e.g. layer-granularity errors) are summed over ranks
         stats = all_reduce_sum(torch.tensor([float(len(layers)), float(rank)]), world)
-        out.put((rank, layers, elapsed, stats.tolist()))
+        # rows of one linear sharded over ranks: a row-independent operator (stand-in for quantize) gives the same
+        # result as unsharded, for even and for ragged splits
+        g = torch.Generator().manual_seed(0)
+        rowwise = lambda w: torch.round(w / w.abs().amax(dim=1, keepdim=True) * 7)  # noqa: E731
+        ok = True
+        for rows, multiple in ((64, 1), (70, 2), (12, 4)):
+            w = torch.randn(rows, 32, generator=g)
+            ok = ok and torch.equal(map_rows_sharded(rowwise, w, world, rank, multiple), rowwise(w))
+        out.put((rank, layers, elapsed, stats.tolist(), ok))
     finally:
         dist.destroy_process_group()
 
@@ -43,10 +52,20 @@ def test_two_rank_sharding_and_reductions():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    all_layers = sorted(i for _, layers, _, _ in results for i in layers)
+    all_layers = sorted(i for _, layers, _, _, _ in results for i in layers)
     assert all_layers == list(range(32)), "every layer is owned by exactly one rank"
-    assert all(elapsed == 2.0 for _, _, elapsed, _ in results), "max over ranks"
-    assert all(stats == [32.0, 1.0] for _, _, _, stats in results)
+    assert all(elapsed == 2.0 for _, _, elapsed, _, _ in results), "max over ranks"
+    assert all(stats == [32.0, 1.0] for _, _, _, stats, _ in results)
+    assert all(ok for *_, ok in results), "row-sharded results equal the unsharded ones"
+
+
+def test_row_shard_partition():
+    for rows, world, multiple in ((4096, 8, 1), (14336, 8, 128), (70, 4, 2), (12, 8, 4), (5, 2, 1)):
+        spans = [row_shard(rows, world, r, multiple) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == rows
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), "contiguous, no overlap"
+        assert all((e - b) % multiple == 0 for b, e in spans)
+        assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= multiple
 
 
 def test_cost_balanced_assignment():
