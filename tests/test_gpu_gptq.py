@@ -179,3 +179,25 @@ def test_gptq_ragged_columns_and_progressive():
         e_gptq = np.square(xn.astype(np.float64) @ (to_np(dq) - wn).T.astype(np.float64)).sum()
         e_rtn = np.square(xn.astype(np.float64) @ (to_np(rtn) - wn).T.astype(np.float64)).sum()
         assert e_gptq < e_rtn, (cname, e_gptq, e_rtn)
+
+
+def test_gptq_row_shards_equal_unsharded():
+    """Rows are independent given the shared Hessian: quantizing row slabs separately (what each rank does when one
+    linear is sharded over GPUs) reproduces the unsharded codes bit for bit."""
+    from deepcompressor_amd.parallel import row_shard
+
+    case = FQ.meta["cases"]["uint4_post_g128_f16s"]
+    g = torch.Generator().manual_seed(21)
+    w = (torch.randn(640, 768, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    x = (torch.randn(3000, 768, generator=g) * torch.exp(0.5 * torch.randn(768, generator=g))).to(torch.bfloat16).cuda()
+    cache = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_samples=3000, orig_device=x.device)
+    q = build_quantizer(case)
+    kern = QuantGptqConfig()
+    full = q.quantize(w, kernel=kern, inputs=cache, return_with_dequant=False, return_with_quant=True).qdata
+    world = 3
+    slabs = []
+    for rank in range(world):
+        b, e = row_shard(w.shape[0], world, rank)
+        slabs.append(q.quantize(w[b:e].contiguous(), kernel=kern, inputs=cache, return_with_dequant=False,
+                                return_with_quant=True).qdata)
+    assert torch.equal(torch.cat(slabs, dim=0), full)
