@@ -21,11 +21,17 @@ constexpr int kNb = 128;  // block size of the factorisation = GEMM tile
 
 // =============================================================================================
 // GEMM  C[M][N] = beta * C + alpha * A * B,  B row-major [K][N]; A either k-major (At[K][M]) or row-major [M][K].
-// Tile 128 x 128 (or 64 x 64 for small problems) per workgroup of 4 waves, K step 32, register-staged double buffer.
+// Tile 128 x 128 (or 64 x 64 for small problems) per workgroup of 4 waves, K step 16 (32 for the small tile), register-staged double buffer.
 // Optional structure: upper_only (skip tiles strictly below the diagonal of C) and triangular operands, for which
 // the k range of a tile is clipped to the part that can be non-zero.
 // =============================================================================================
-constexpr int kGK = 32;  // K step
+constexpr int kGKMin = 16;  // K must be a multiple of every K step in use
+template <int T>
+struct GemmStep {
+  // K step per tile size: 128-tiles run 4 workgroups per CU on a short step; 64-tiles (latency-bound small
+  // problems) take fewer, longer steps
+  static constexpr int value = T == 128 ? 16 : 32;
+};
 constexpr int kGemmThreads = 256;
 
 struct GemmParams {
@@ -62,9 +68,11 @@ __device__ __forceinline__ float4 load_piece(const float* row, int col, int limi
 // T = 128 for throughput; T = 64 spreads small problems over 4x as many compute units (latency-bound regime).
 template <bool A_KMAJOR, bool FAST, int T>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m0, int n0, int k_begin, int nk) {
+  constexpr int kGK = GemmStep<T>::value;
   constexpr int LD = T + 4;              // LDS row pitch: the two half-waves of a fragment read hit different banks
   constexpr int IMG = kGK * LD;          // one operand image [k][m or n]
-  constexpr int PIECES = T / 32;         // 16-byte pieces per thread, operand and k-step
+  constexpr int PIECES = kGK * T / 4 / kGemmThreads;  // 16-byte pieces per thread, operand and k-step
+  constexpr int KP = kGK / 4;            // pieces per row of a row-major A tile
   constexpr int F = T / 64;              // 32 x 32 tiles per wave and dimension
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -80,7 +88,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m
       if (A_KMAJOR) {
         ra[it] = load_piece<FAST>(p.A + static_cast<int64_t>(k0 + kr) * p.lda, m0 + c4, p.M);
       } else {
-        const int mr = id >> 3, k4 = (id & 7) * 4;
+        const int mr = id / KP, k4 = (id % KP) * 4;
         const int m = m0 + mr;
         const float* row = p.A + static_cast<int64_t>(min(m, p.M - 1)) * p.lda + k0;
         float4 v = load_piece<FAST>(row, k4, kGK);  // K is a multiple of the step: only alignment can be missing
@@ -100,7 +108,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m
       if (A_KMAJOR) {
         *reinterpret_cast<float4*>(la + kr * LD + c4) = ra[it];
       } else {
-        const int mr = id >> 3, k4 = (id & 7) * 4;
+        const int mr = id / KP, k4 = (id % KP) * 4;
         la[(k4 + 0) * LD + mr] = ra[it].x;
         la[(k4 + 1) * LD + mr] = ra[it].y;
         la[(k4 + 2) * LD + mr] = ra[it].z;
@@ -161,11 +169,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m
 }
 
 template <bool A_KMAJOR, int T>
-__global__ __launch_bounds__(kGemmThreads, T == 128 ? 2 : 4) void gemm_f32_kernel(const GemmParams p) {
+__global__ __launch_bounds__(kGemmThreads, 4) void gemm_f32_kernel(const GemmParams p) {
   extern __shared__ __align__(16) unsigned char gemm_smem[];
   float* lds = reinterpret_cast<float*>(gemm_smem);  // [buffer][A | B][k][m or n]
   const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
   if (p.upper_only && tn < tm) return;
+  constexpr int kGK = GemmStep<T>::value;
   const int m0 = tm * T, n0 = tn * T;
   int k_begin = 0, k_end = p.K;
   if (p.k_above_m) k_begin = max(k_begin, m0 / kGK * kGK);
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(kGemmThreads, T == 128 ? 2 : 4) void gemm_f32_kerne
 
 template <bool A_KMAJOR, int T>
 static int launch_gemm_variant(const GemmParams& p, hipStream_t s) {
-  constexpr size_t lds = 2 * 2 * kGK * (T + 4) * sizeof(float);
+  constexpr size_t lds = 2 * 2 * GemmStep<T>::value * (T + 4) * sizeof(float);
   auto kern = gemm_f32_kernel<A_KMAJOR, T>;
   static bool configured[64] = {};
   int dev = 0;
@@ -488,7 +497,7 @@ int dcq_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, 
   DCQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, DCQ_ERR_ARGUMENT, "negative size");
   if (M == 0 || N == 0) return DCQ_OK;
   DCQ_REQUIRE(A && B && C, DCQ_ERR_ARGUMENT, "NULL buffer");
-  DCQ_REQUIRE(K % kGK == 0, DCQ_ERR_UNSUPPORTED, "K must be a multiple of %d (got %lld)", kGK, (long long)K);
+  DCQ_REQUIRE(K % 32 == 0, DCQ_ERR_UNSUPPORTED, "K must be a multiple of 32 (got %lld)", (long long)K);
   DCQ_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), DCQ_ERR_UNSUPPORTED, "size too large");
   GemmParams g{};
   g.A = A;
