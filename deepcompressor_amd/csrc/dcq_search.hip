@@ -59,6 +59,38 @@ __device__ __forceinline__ float from_bits16(uint16_t b) {
   return ST == DCQ_BF16 ? bf16_to_f32(b) : f16_to_f32(b);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// two float32 -> two 16-bit patterns in one register (low half = first), round-to-nearest-even, hardware converts
+template <int ST>
+__device__ __forceinline__ uint32_t to_bits16x2(f32x2 v) {
+  if (ST == DCQ_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+template <int ST>
+__device__ __forceinline__ f32x2 from_bits16x2(uint32_t b) {
+  if (ST == DCQ_BF16) return f32x2{__uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+  return __builtin_convertvector(__builtin_bit_cast(f16x2, b), f32x2);
+}
+
+// IEEE-exact division by a per-candidate scale with the reciprocal part hoisted: y = rcp(s) refined by one Newton
+// step, q0 = x*y and two residual corrections -- the hardware's own division sequence without its range fix-ups,
+// valid while 2^-60 <= s <= 2^60 and |x| <= 2^60 (checked per candidate; otherwise the plain division runs).
+__device__ __forceinline__ float refined_rcp(float s) {
+  const float y0 = __builtin_amdgcn_rcpf(s);
+  return __builtin_fmaf(__builtin_fmaf(-s, y0, 1.0f), y0, y0);
+}
+__device__ __forceinline__ f32x2 div_hoisted2(f32x2 x, float s, float y) {
+  const f32x2 y2 = {y, y}, ns = {-s, -s};
+  f32x2 q = x * y2;
+  f32x2 r = __builtin_elementwise_fma(ns, q, x);
+  q = __builtin_elementwise_fma(r, y2, q);
+  r = __builtin_elementwise_fma(ns, q, x);
+  return __builtin_elementwise_fma(r, y2, q);
+}
+
 // lane i of each 16-lane row receives lane i-1's value (row_shr:1)
 __device__ __forceinline__ float row_shift_right1(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
@@ -147,6 +179,13 @@ __global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const S
         bmin = fminf(bmin, 0.0f);
       }
     }
+    // packed integer path (16-bit weights): largest |x| of the group, for the guard of the hoisted division
+    constexpr bool PACKED = INT_Q && ST != DCQ_F32 && POW != kPowFloat && NPL % 2 == 0;
+    float gabs = 0.0f;
+    if (PACKED) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) gabs = fmaxf(gabs, fabsf(x[i]));
+    }
     float best_err = 0.0f;
     int best_k = 0;
     for (int k = 0; k < p.K; ++k) {
@@ -159,8 +198,42 @@ __global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const S
       }
       const ScaleZero sz = scale_zero_from_range(st, cmax, cmin, cbs + 256, cbs + 512);
       float pw[NPL];
+      bool done = false;
+      if (PACKED) {
+        const bool ok = sz.s >= 0x1p-60f && sz.s <= 0x1p60f && gabs + fabsf(sz.z) <= 0x1p60f;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) {  // uniform over the wave
+          done = true;
+          const float y = refined_rcp(sz.s);
+          const f32x2 z2 = {sz.z, sz.z}, s2 = {sz.s, sz.s}, lo2 = {st.tensor.lo, st.tensor.lo}, hi2 = {st.tensor.hi, st.tensor.hi};
+#pragma unroll
+          for (int i = 0; i < NPL; i += 2) {
+            const f32x2 xv = {x[i], x[i + 1]};
+            f32x2 t = ZD == DCQ_ZERO_POST_SCALE ? xv + z2 : xv;
+            t = div_hoisted2(t, sz.s, y);
+            if (ZD == DCQ_ZERO_PRE_SCALE) t = t + z2;
+            f32x2 q = {rintf(t.x), rintf(t.y)};
+            q = __builtin_elementwise_min(__builtin_elementwise_max(q, lo2), hi2);
+            f32x2 d;
+            if (ZD == DCQ_ZERO_PRE_SCALE) d = (q - z2) * s2;
+            else if (ZD == DCQ_ZERO_POST_SCALE) d = q * s2 - z2;
+            else d = q * s2;
+            const f32x2 dq = from_bits16x2<ST>(to_bits16x2<ST>(d));          // Q(w) in the weight dtype
+            const uint32_t eb = to_bits16x2<ST>(dq - xv) & 0x7fff7fffu;      // |Q(w) - w| in the weight dtype
+            if (POW == kPowTable) {
+              pw[i] = from_bits16<ST>(table[eb & 0xffffu]);
+              pw[i + 1] = from_bits16<ST>(table[eb >> 16]);
+            } else {
+              const f32x2 a = from_bits16x2<ST>(eb);
+              const f32x2 sq = from_bits16x2<ST>(to_bits16x2<ST>(a * a));
+              pw[i] = sq.x;
+              pw[i + 1] = sq.y;
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
+        if (done) break;
         const float t = to_code_input<ZD>(x[i], sz.s, sz.z);
         const float q = INT_Q ? round_int(t, st.tensor.lo, st.tensor.hi) : apply_rounding(st.tensor, t, cbs);
         const float d = from_code<ZD>(q, sz.s, sz.z);
