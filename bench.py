@@ -208,6 +208,13 @@ def main() -> None:
         tiles = lambda c: (-(-c // 256)) * (-(-c // 256) + 1) // 2  # noqa: E731
         exec_flop = sum(2.0 * args.tokens * tiles(c) * 256 * 256 for _, _, c in syrk_events)
         achieved = syrk_flop / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+        # HBM-side bytes per launch of that kernel, from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, see the
+        # file for the method); only valid for the contract workload it was measured on
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_syrk_traffic.json")
+        if args.tokens == 128 * 2048 and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f)["avg_hbm_bytes_per_launch"]
         line = {
             "metric": "quantized params/sec (whole node), Llama-3-8B GPTQ W4 g128 + range search",
             "value": total_params / elapsed, "unit": "params/s", "n_gpus": world, "steps": args.steps,
@@ -219,7 +226,7 @@ def main() -> None:
                        "params_per_step": PARAMS_PER_LAYER, "tokens": args.tokens,
                        "parallelism": f"independent layers x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": achieved / 2500.0, "traffic": None, "kernel": "syrk_kernel (H += 2/n X^T X, bf16 MFMA)",
+                         "frac": achieved / 2500.0, "traffic": traffic, "kernel": "syrk_kernel (H += 2/n X^T X, bf16 MFMA)",
                          "launches": len(syrk_events), "avg_launch_ms": syrk_ms / max(1, len(syrk_events)),
                          "share_of_step": syrk_ms * 1e-3 / elapsed,
                          "executed_tflops": exec_flop / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0},
