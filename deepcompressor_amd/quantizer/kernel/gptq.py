@@ -117,11 +117,15 @@ def release_workspaces() -> None:
 
 
 def hessian_accumulate(hessian: torch.Tensor, x: torch.Tensor, alpha: float) -> None:
-    """hessian[C][C] += alpha * x^T x for x[N][C] (float16 / bfloat16, on the same GPU)."""
+    """hessian[C][C] += alpha * x^T x for x[N][C] on the same GPU: 16-bit activations take the bf16 / f16
+    matrix-core SYRK, float32 activations the float32 matrix-core GEMM (x^T is the transposed-A operand)."""
     assert x.ndim == 2 and hessian.shape == (x.shape[1], x.shape[1]) and hessian.dtype == torch.float32
-    if x.dtype == torch.float32:
-        raise NotImplementedError("float32 calibration activations are not implemented (float16 / bfloat16 are)")
     x = x.contiguous()
+    if x.dtype == torch.float32:
+        if x.shape[0] % 32:  # the GEMM steps K in multiples of 32: zero rows add nothing
+            x = torch.cat([x, x.new_zeros(32 - x.shape[0] % 32, x.shape[1])], dim=0)
+        gemm_f32(x, x, hessian, alpha=float(alpha), beta=1.0, a_transposed=True)
+        return
     T, Cn = x.shape
     nbytes = lib().dcq_hessian_workspace_bytes(T, Cn)
     ws = _workspace(x.device, nbytes)

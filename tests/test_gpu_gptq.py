@@ -42,6 +42,18 @@ def test_hessian_matches_float64(T, C, dt):
     assert got[3, 3] == 0
 
 
+def test_hessian_float32_activations():
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(1001, 264, generator=g) * torch.exp(torch.randn(264, generator=g))
+    H = torch.zeros(264, 264, device="cuda")
+    hessian_accumulate(H, x.cuda(), 2.0 / 1001)
+    hessian_accumulate(H, x.cuda(), 2.0 / 1001)
+    want = (x.double().T @ x.double()) * (4.0 / 1001)
+    scale = want.diagonal().sqrt()
+    rel = ((H.cpu().double() - want).abs() / (scale[:, None] * scale[None, :])).max().item()
+    assert rel < 5e-6, rel
+
+
 @pytest.mark.parametrize("M,N,K,a_t", [(128, 128, 32, False), (96, 200, 128, False), (300, 515, 64, True),
                                        (1024, 2048, 128, False), (257, 129, 256, True), (4, 4, 32, False), (131, 77, 64, True), (131, 77, 64, False),
                                        (2950, 3075, 64, False), (2950, 3076, 32, True)])
