@@ -384,7 +384,7 @@ static HessianPlan plan_hessian(int64_t T, int64_t C) {
 constexpr int kSweepCols = 128;     // columns per block (the reference's block_size)
 constexpr int kSweepTeam = 16;      // lanes per row
 constexpr int kSweepPerLane = 8;    // columns per lane
-constexpr int kSweepThreads = 512;  // 8 waves = 32 rows per workgroup
+constexpr int kSweepThreads = 512;  // largest workgroup: 8 waves = 32 rows; the launch picks 64..512 from the row count
 
 struct SweepParams {
   dcq_step step;
@@ -404,6 +404,7 @@ struct SweepParams {
   float* Q;    // [R][ldw] codes, permuted order
   float* Err;  // [R][ld_err], 128 columns used
   int64_t ld_err;
+  int32_t u_quads;  // the block of U may be read as aligned float4
 };
 
 template <int ZD, bool INT_Q>
@@ -411,20 +412,36 @@ __global__ __launch_bounds__(kSweepThreads) void gptq_sweep_kernel(const SweepPa
   extern __shared__ __align__(16) unsigned char smem[];
   float* u_lds = reinterpret_cast<float*>(smem);           // [128][128], rows >= bc / cols >= bc zero
   float* cb = u_lds + kSweepCols * kSweepCols;             // tensor codebook [256]
-  // stage the diagonal block of U (only the upper triangle is ever read)
-  for (int e = threadIdx.x; e < kSweepCols * kSweepCols; e += kSweepThreads) {
-    const int r = e / kSweepCols, c = e % kSweepCols;
-    float v = 0.0f;
-    if (r < p.bc && c < p.bc && c >= r) v = p.U[(p.c0 + r) * p.C + p.c0 + c];
-    u_lds[e] = v;
+  // stage the diagonal block of U four columns at a time; entries left of the diagonal are never used with a
+  // non-zero meaning, so quads wholly below it are written as zeros without touching memory
+  const int threads = static_cast<int>(blockDim.x);
+  const bool quads = p.u_quads != 0;
+  for (int e = threadIdx.x; e < kSweepCols * kSweepCols / 4; e += threads) {
+    const int r = e / (kSweepCols / 4), c = (e % (kSweepCols / 4)) * 4;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (r < p.bc && c + 3 >= r && c < p.bc) {
+      const float* src = p.U + (p.c0 + r) * p.C + p.c0 + c;
+      if (quads && c + 3 < p.bc) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        v.x = src[0];
+        if (c + 1 < p.bc) v.y = src[1];
+        if (c + 2 < p.bc) v.z = src[2];
+        if (c + 3 < p.bc) v.w = src[3];
+      }
+      if (c < r) v.x = 0.0f;
+      if (c + 1 < r) v.y = 0.0f;
+      if (c + 2 < r) v.z = 0.0f;
+    }
+    *reinterpret_cast<float4*>(u_lds + r * kSweepCols + c) = v;
   }
   if (!INT_Q)
-    for (int i = threadIdx.x; i < p.step.tensor.codebook_size; i += kSweepThreads) cb[i] = p.step.tensor.codebook[i];
+    for (int i = threadIdx.x; i < p.step.tensor.codebook_size; i += threads) cb[i] = p.step.tensor.codebook[i];
   __syncthreads();
 
   const int tl = threadIdx.x & (kSweepTeam - 1);
   const int team = threadIdx.x / kSweepTeam;
-  const int teams_per_block = kSweepThreads / kSweepTeam;
+  const int teams_per_block = threads / kSweepTeam;
   const dcq_step& st = p.step;
   for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * teams_per_block; row0 < p.R;
        row0 += static_cast<int64_t>(gridDim.x) * teams_per_block) {
@@ -607,7 +624,13 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
   p.Err = Err;
   p.ld_err = ld_err;
   const size_t lds = kSweepCols * kSweepCols * 4 + 256 * 4;
-  const int rows_per_block = kSweepThreads / kSweepTeam;
+  p.u_quads = (reinterpret_cast<uintptr_t>(U) & 15u) == 0 && C % 4 == 0 && c0 % 4 == 0;
+  // One column step costs a wave the same whether 4 or 1 of its rows are live, and the 64 KiB block of U lets two
+  // workgroups share a CU: spread the rows over 512 workgroups (two per CU) of whole waves, at most 8 waves each.
+  int64_t rows_per_block = (R + 511) / 512;
+  rows_per_block = (rows_per_block + 3) / 4 * 4;
+  if (rows_per_block > kSweepThreads / kSweepTeam) rows_per_block = kSweepThreads / kSweepTeam;
+  const int sweep_threads = static_cast<int>(rows_per_block) * kSweepTeam;
   int64_t blocks = (R + rows_per_block - 1) / rows_per_block;
   if (blocks > 1024) blocks = 1024;
   const bool int_q = step->tensor.kind == DCQ_ROUND_INT;
@@ -619,7 +642,7 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)), \
                        "hipFuncSetAttribute(sweep LDS)");                                                    \
     if (rc != DCQ_OK) return rc;                                                                             \
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kSweepThreads), lds, s, p);           \
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(sweep_threads), lds, s, p);           \
   } while (0)
   switch (step->zero_domain) {
     case DCQ_ZERO_NONE:
