@@ -76,7 +76,9 @@ _SIGNATURES = {
     "dcq_gemm_f64": [_p, _i32, _i64, _i32, _i64, _p, _i32, _i64, _i64, _p, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "dcq_channel_metric": [_p, _i32, _i64, _i64, _i64, _i32, _p, _p, _p],
     "dcq_scale_channels": [_p, _i32, _i64, _i64, _i64, _p, _i64, _i32, _p, _i32, _p],
-    "dcq_range_search_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _i32, _d, _p, _p, _p, _p, _p, _p, _p],
+    "dcq_range_search_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _i32, _d, _p, _p, _p, _p, _p, _p, _i32,
+                                _p],
+    "dcq_group_error": [_p, _p, _i32, _i64, _i64, _d, _p, _p, _p],
 }
 _lib = None
 

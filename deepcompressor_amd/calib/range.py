@@ -1,8 +1,15 @@
 """Dynamic-range calibration (reference: deepcompressor/calib/range.py:25-474, calib/search.py:63-837).
 
 The reference proposes one ratio at a time (ask), fake-quantizes the whole tensor, measures the error and
-keeps the best (tell).  Here the weight / tensor-error / per-group search is ONE kernel launch that evaluates
-every candidate of every group from registers (``dcq_range_search_groups``); the result is identical.
+keeps the best (tell).  Two device paths produce the same result here:
+
+* fused -- single-step quantizer, one scale level, groups of at most 512 contiguous values: ONE kernel launch
+  evaluates every candidate of every group from registers (``dcq_range_search_groups``); Group granularity
+  takes the per-group winners straight from the kernel, ChannelGroup / Layer add the per-candidate group sums
+  up over rows / the whole tensor first;
+* general -- anything else the weight search covers (a step of a progressive quantizer with the previous
+  steps' scale, multi-level scales, long or non-contiguous groups): the ask/tell loop itself, each candidate
+  fake-quantized by the HIP quantizer and scored by ``dcq_group_error``.
 """
 
 from __future__ import annotations
@@ -16,7 +23,9 @@ from .. import engine
 from ..data.cache import TensorsCache
 from ..data.common import TensorType
 from ..data.range import DynamicRange
+from ..data.scale import QuantScale
 from ..data.utils.shape import infer_view_shape
+from ..quantizer.impl.info import QuantInfo
 from ..quantizer.processor import Quantizer
 from .config import (DynamicRangeCalibConfig, SearchBasedCalibGranularity, SearchBasedCalibObjective)
 
@@ -24,7 +33,7 @@ __all__ = ["DynamicRangeCalibrator", "calibrate_dynamic_range"]
 
 
 class DynamicRangeCalibrator:
-    """Finds the per-group (min, max) that minimises the quantization error of a tensor."""
+    """Finds the (min, max) per group / channel group / tensor that minimises the quantization error of a tensor."""
 
     def __init__(self, tensor_type: TensorType, config: DynamicRangeCalibConfig, static: bool, quantizer: Quantizer,
                  pre_scale: torch.Tensor | None = None) -> None:
@@ -35,18 +44,56 @@ class DynamicRangeCalibrator:
         self.objective, self.granularity = config.objective, config.granularity
         self.ratios = config.get_ratios()
         self.num_iters = len(self.ratios)
+        self.base_range = DynamicRange()
         self.best_range = DynamicRange()
         self.best_error: torch.Tensor | None = None
         self.candidate_errors: torch.Tensor | None = None
+        self.path: str | None = None  # "fused" or "general", for tests and logs
 
     def is_clamp_based(self) -> bool:
         return self.static or not self.config.allow_scale
 
     def _unsupported(self, what: str):
         return NotImplementedError(
-            f"range calibration with {what} is not implemented by the HIP search kernel "
-            "(implemented: weights, TensorError objective, Group granularity, static / clamp-based range)")
+            f"range calibration with {what} is not implemented on the device "
+            "(implemented: weights, TensorError objective, static / clamp-based range, any granularity)")
 
+    # ---- shapes (calib/range.py:113-139) ---------------------------------------------------------------------
+    def _set_shapes(self, shape: torch.Size) -> None:
+        view = infer_view_shape(shape, self.quantizer.config.largest_group_shape)
+        self.view_shape = view
+        self.pos_view_shape = torch.Size([1, 1, view[2], *([1] * (len(view) - 3))])
+        self.range_shape = torch.Size([gs if i % 2 == 0 else 1 for i, gs in enumerate(view)])
+        if self.granularity == SearchBasedCalibGranularity.Layer:
+            self.ratio_shape = self.error_shape = torch.Size((1,))
+            self.ratio_view_shape = self.ratio_shape
+        elif self.granularity == SearchBasedCalibGranularity.ChannelGroup:
+            self.ratio_shape = self.error_shape = torch.Size((view[2],))
+            self.ratio_view_shape = self.pos_view_shape
+        elif self.granularity == SearchBasedCalibGranularity.Group:
+            self.ratio_shape = self.error_shape = torch.Size(view[::2])
+            self.ratio_view_shape = self.range_shape
+        else:
+            raise ValueError(f"Invalid granularity: {self.granularity}")
+        if self.pre_scale is not None:
+            assert len(shape) * 2 == len(self.pre_scale.shape)
+            self.pre_view_shape = infer_view_shape(shape, self.pre_scale.shape[1::2])
+        else:
+            self.pre_view_shape = torch.Size()
+
+    def _reduce(self, raw: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        """Unrounded float32 group sums shaped (..., *view[::2]) -> the error tensor of this granularity in the
+        weight's dtype (calib/search.py:780-787: the reference's sum runs in that dtype, accumulating in float32
+        and rounding once; groups are added up in float64 here, so a Layer / ChannelGroup error can differ from
+        the reference's by one unit in the last place of ``dtype`` when the float32 total sits on a rounding edge)."""
+        lead = raw.ndim - len(self.view_shape[::2])
+        if self.granularity == SearchBasedCalibGranularity.Group:
+            return raw.to(dtype)
+        dims = [lead + i for i in range(len(self.view_shape[::2]))
+                if not (self.granularity == SearchBasedCalibGranularity.ChannelGroup and i == 1)]
+        return raw.double().sum(dim=dims).view(*raw.shape[:lead], *self.error_shape).to(dtype)
+
+    # ---- entry -------------------------------------------------------------------------------------------------
     def calibrate(self, x_wgts: list[nn.Parameter] | None = None, *, record_errors: bool = False,
                   **unused) -> DynamicRange:
         """Run the whole grid search; extra reference keyword arguments (eval_inputs, modules...) are accepted
@@ -55,38 +102,141 @@ class DynamicRangeCalibrator:
             raise self._unsupported(f"tensor type {self.tensor_type.name}")
         if self.objective != SearchBasedCalibObjective.TensorError:
             raise self._unsupported(f"objective {self.objective.name}")
-        if self.granularity != SearchBasedCalibGranularity.Group:
-            raise self._unsupported(f"granularity {self.granularity.name}")
         if not self.is_clamp_based():
             raise self._unsupported("allow_scale on a non-static tensor")
-        if self.pre_scale is not None:
-            raise self._unsupported("progressive (multi-step) quantizers")
         assert x_wgts is not None and len(x_wgts) == 1, "The weight should be a single tensor."
         w = x_wgts[0].detach().data
+        self._set_shapes(w.shape)
         q = self.quantizer
-        default_dtype = w.dtype  # the search fake-quantizes with default_dtype = the weight's dtype
-        info = q.update(w.shape, default_dtype=default_dtype)
-        if info.num_steps != 1 or not info.steps[0].scale.is_single_level():
-            raise self._unsupported("multi-level scales")
-        step_info = info.steps[0]
-        view = infer_view_shape(w.shape, q.config.largest_group_shape)
-        assert tuple(view) == tuple(step_info.tensor_view_shape)
+        info = q.update(w.shape, default_dtype=w.dtype)  # the search fake-quantizes with default_dtype = w.dtype
+        group_size = 1
+        for s in self.view_shape[1::2]:
+            group_size *= s
+        fused = (self.pre_scale is None and info.num_steps == 1 and info.steps[0].scale.is_single_level()
+                 and tuple(info.steps[0].tensor_view_shape) == tuple(self.view_shape) and group_size <= 512
+                 and group_size % (8 if w.dtype == torch.float32 else 16) == 0
+                 and not (q.range_bound is not None and q.range_bound.is_set()))
+        self.path = "fused" if fused else "general"
+        if fused:
+            self._calibrate_fused(w, info.steps[0], record_errors)
+        else:
+            self._calibrate_general(w, record_errors)
+        return self.get_best()
+
+    # ---- fused path --------------------------------------------------------------------------------------------
+    def _calibrate_fused(self, w: torch.Tensor, step_info, record_errors: bool) -> None:
+        view = self.view_shape
         x2d, _ = engine.canonical_groups(w, view)
         ratios = [r for it in self.ratios for r in it]
+        group = self.granularity == SearchBasedCalibGranularity.Group
         out = engine.range_search_groups(step_info.scale.native(w.device), x2d, ratios, float(self.config.degree),
-                                         want_errors=record_errors)
-        keep = [v if i % 2 == 0 else 1 for i, v in enumerate(view)]
-        self.best_range = DynamicRange(min=out["min"].view(keep) if out["min"] is not None else None,
-                                       max=out["max"].view(keep), ratio=out["ratio"].view(view[::2]))
-        self.best_error = out["error"].view(view[::2]).to(w.dtype)
+                                         want_errors=record_errors or not group, unrounded_errors=not group)
+        if group:
+            self.best_range = DynamicRange(min=out["min"].view(self.range_shape) if out["min"] is not None else None,
+                                           max=out["max"].view(self.range_shape), ratio=out["ratio"].view(view[::2]))
+            self.best_error = out["error"].view(view[::2]).to(w.dtype)
+            if record_errors:
+                self.candidate_errors = out["errors"].view(len(ratios), *view[::2])
+            return
+        errors = self._reduce(out["errors"].view(len(ratios), *view[::2]), w.dtype)  # [K, *error_shape]
+        self.best_error, first = _first_strict_min(errors)
+        r32 = torch.tensor(ratios, dtype=torch.float64).to(torch.float32).to(w.device)
+        self.base_range = DynamicRange.construct(
+            w.view(view), zero_domain=q_zero_domain(self.quantizer),
+            is_float_point=self.quantizer.config.quant_dtype.is_float_point)
+        best = self.base_range.scale(r32[first].view(self.ratio_view_shape), q_zero_domain(self.quantizer),
+                                     self.quantizer.config.quant_dtype.is_float_point)
+        self.best_range = DynamicRange(min=None if best.min is None else best.min.expand(self.range_shape).contiguous(),
+                                       max=best.max.expand(self.range_shape).contiguous(),
+                                       ratio=r32[first].view(self.ratio_shape))
         if record_errors:
-            self.candidate_errors = out["errors"].view(len(ratios), *view[::2])
-        return self.get_best()
+            self.candidate_errors = errors
+
+    # ---- general path: the reference's ask / tell loop --------------------------------------------------------
+    def _preprocess_with_pre_scale(self, t: torch.Tensor) -> torch.Tensor:
+        """clamp(t / pre_scale, range_bound) in float32, shaped like t (calib/range.py:252-258)."""
+        # one group per value of the previous scale: the block of the tensor that value is broadcast over
+        block = [dim // n for dim, n in zip(t.shape, self.pre_scale.shape[0::2])]
+        x2d, restore = engine.canonical_groups(t, infer_view_shape(t.shape, block))
+        rb = self.quantizer.range_bound
+        lo = rb.min if rb is not None and rb.min is not None else float("-inf")
+        hi = rb.max if rb is not None and rb.max is not None else float("inf")
+        outer = self.pre_scale.to(torch.float32).contiguous().view(-1)
+        return restore(engine.prescale_groups(x2d, outer, float(lo), float(hi)))
+
+    def _process_wxy(self, tensor: torch.Tensor, candidate: DynamicRange) -> torch.Tensor:
+        """The fake-quantized tensor of one candidate, in the tensor's dtype (calib/range.py:260-275)."""
+        shape, dtype = tensor.shape, tensor.dtype
+        if self.pre_scale is not None:
+            tensor = self._preprocess_with_pre_scale(tensor).view(shape)
+        tensor = self.quantizer.quantize(tensor, kernel=None, channels_dim=None, dynamic_range=candidate,
+                                         default_dtype=dtype, develop_dtype=self.develop_dtype).data
+        if self.pre_scale is not None:
+            tensor = tensor.view(self.pre_view_shape).mul_(self.pre_scale).to(dtype)
+        return tensor.view(shape)
+
+    def _calibrate_general(self, w: torch.Tensor, record_errors: bool) -> None:
+        view = self.view_shape
+        zd = q_zero_domain(self.quantizer)
+        is_fp = self.quantizer.config.quant_dtype.is_float_point
+        t = self._preprocess_with_pre_scale(w) if self.pre_scale is not None else w
+        self.base_range = DynamicRange.construct(t.view(view).to(self.develop_dtype), zero_domain=zd, is_float_point=is_fp)
+        del t
+        b2d, _ = engine.canonical_groups(w, view)
+        self.best_range, self.best_error = DynamicRange(), None
+        history = []
+        for iteration in self.ratios:
+            for ratio in iteration:
+                candidate = self.base_range.scale(ratio=ratio, zero_domain=zd, is_float_point=is_fp)
+                a2d, _ = engine.canonical_groups(self._process_wxy(w, candidate), view)
+                raw = engine.group_error(a2d, b2d, float(self.config.degree)).view(view[::2])
+                error = self._reduce(raw, w.dtype)
+                if record_errors:
+                    history.append(error.clone())
+                self._tell_general(error, candidate, ratio, w.device)
+        if record_errors:
+            self.candidate_errors = torch.stack(history)
+
+    def _tell_general(self, error: torch.Tensor, candidate: DynamicRange, ratio: float, device) -> None:
+        """calib/range.py:183-221.  Per channel group the reference's own update cannot run (it reshapes the mask
+        expanded over rows to the per-channel-group ratio shape, calib/range.py:208-215, which raises); the mask is
+        applied to the ratio before it is expanded here."""
+        if self.best_error is None:
+            self.best_error = error.clone()
+            self.best_range.min = None if candidate.min is None else candidate.min.expand(self.range_shape).clone()
+            self.best_range.max = candidate.max.expand(self.range_shape).clone()
+            self.best_range.ratio = torch.full(size=self.ratio_shape, fill_value=ratio, device=device,
+                                               dtype=self.develop_dtype)
+            return
+        pos = error < self.best_error  # strict: the earlier (larger) ratio wins ties
+        self.best_error[pos] = error[pos]
+        self.best_range.ratio[pos.view(self.ratio_shape)] = ratio
+        if self.granularity == SearchBasedCalibGranularity.Group:
+            rpos = pos.view(self.range_shape)
+        elif self.granularity == SearchBasedCalibGranularity.ChannelGroup:
+            rpos = pos.view(self.pos_view_shape).expand(*self.range_shape)
+        else:
+            rpos = pos.view([1] * len(self.range_shape)).expand(*self.range_shape)
+        self.best_range.max[rpos] = candidate.max.expand(self.range_shape)[rpos]
+        if isinstance(candidate.min, torch.Tensor):
+            self.best_range.min[rpos] = candidate.min.expand(self.range_shape)[rpos]
 
     def get_best(self) -> DynamicRange:
         if self.static:
             return DynamicRange(min=self.best_range.min, max=self.best_range.max)
         return DynamicRange(min=self.best_range.min, max=self.best_range.max, ratio=1.0)
+
+
+def q_zero_domain(quantizer: Quantizer):
+    return quantizer.config.zero_domain
+
+
+def _first_strict_min(errors: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """errors[K, ...] -> (smallest error, index of the first candidate reaching it): what the reference's
+    'replace when strictly smaller' update keeps."""
+    best = errors.min(dim=0).values
+    first = (errors == best.unsqueeze(0)).to(torch.uint8).argmax(dim=0)
+    return best, first
 
 
 def calibrate_dynamic_range(tensor_type: TensorType, config: DynamicRangeCalibConfig | None, static: bool,
@@ -95,10 +245,11 @@ def calibrate_dynamic_range(tensor_type: TensorType, config: DynamicRangeCalibCo
                             eval_module: nn.Module | None = None, eval_kwargs: dict[str, tp.Any] | None = None,
                             orig_weights=None, orig_activations=None, orig_eval_inputs=None
                             ) -> tp.Sequence[DynamicRange] | None:
-    """Per-step dynamic ranges of ``quantizer`` (None when nothing has to be stored)."""
+    """Per-step dynamic ranges of ``quantizer`` (None when nothing has to be stored); calib/range.py:302-474."""
     if config is None or not quantizer.is_enabled():
         return None
-    num_steps = quantizer.config.decompose().num_steps
+    decomposed = quantizer.config.decompose()
+    num_steps = decomposed.num_steps
     if not config.needs_search and (not static or tensor_type == TensorType.Weights):
         if config.ratio != 1.0:
             return tuple([DynamicRange(ratio=config.ratio)] + [None] * (num_steps - 1))
@@ -107,7 +258,32 @@ def calibrate_dynamic_range(tensor_type: TensorType, config: DynamicRangeCalibCo
         weights = [m.weight for m in modules if hasattr(m, "weight")]
     if tensor_type == TensorType.Weights:
         assert len(modules) == 1 and len(weights) == 1, "only one module / weight per weight-range calibration"
-    if num_steps != 1:
-        raise NotImplementedError("range search for progressive (multi-step) quantizers is not implemented")
-    calibrator = DynamicRangeCalibrator(tensor_type=tensor_type, config=config, static=static, quantizer=quantizer)
-    return (calibrator.calibrate(x_wgts=list(weights)),)
+    if num_steps == 1:
+        calibrator = DynamicRangeCalibrator(tensor_type=tensor_type, config=config, static=static, quantizer=quantizer)
+        return (calibrator.calibrate(x_wgts=list(weights)),)
+    # progressive quantizer: one calibrator per step, each seeing the tensor divided by the scales found so far
+    if tensor_type != TensorType.Weights:
+        raise NotImplementedError("progressive range search is implemented for weights only")
+    tensor = weights[0].detach().data
+    develop_dtype = quantizer.develop_dtype
+    default_scale_dtype = quantizer.default_dtype or tensor.dtype
+    develop_tensor = tensor.to(dtype=develop_dtype) if tensor.dtype != develop_dtype else tensor.clone()
+    info = QuantInfo.construct(decomposed, tensor_shape=develop_tensor.shape, default_dtype=default_scale_dtype,
+                               quant_range=quantizer.quant_range, range_bound=quantizer.range_bound)
+    dynamic_ranges, quant_scale = [], QuantScale()
+    for step, step_info in enumerate(info.steps):
+        step_quantizer = Quantizer(config=step_info.to_config(), kernel=quantizer.kernel if step == num_steps - 1 else None,
+                                   quant_range=step_info.quant_range, range_bound=step_info.range_bound,
+                                   default_dtype=quantizer.default_dtype, develop_dtype=quantizer.develop_dtype)
+        step_range = DynamicRangeCalibrator(tensor_type=tensor_type, config=config, static=static,
+                                            quantizer=step_quantizer, pre_scale=quant_scale.data
+                                            ).calibrate(x_wgts=list(weights))
+        dynamic_ranges.append(step_range)
+        step_scale, _ = step_info.scale.quantize(tensor=develop_tensor.view(step_info.tensor_shape),
+                                                 dynamic_range=step_range)
+        quant_scale.append(step_scale)
+        if num_steps > 2 and step < num_steps - 1:
+            step_quant_range = step_info.tensor_quant_range
+            develop_tensor = develop_tensor.view(step_info.tensor_view_shape).div_(step_scale.data)
+            develop_tensor = develop_tensor.clamp_(min=step_quant_range.min, max=step_quant_range.max)
+    return tuple(dynamic_ranges)

@@ -42,6 +42,7 @@ struct SearchParams {
   float* best_ratio;
   float* best_error;
   float* errors;
+  int32_t errors_unrounded;
 };
 
 // hardware float32 -> bfloat16 (round-to-nearest-even) used in the hot loop
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const S
         y = j == 0 ? part : prev + part;
       }
       const float err = St::round(y);  // valid in lane j == 7
-      if (p.errors && j == kTeam - 1 && live) p.errors[static_cast<int64_t>(k) * p.G + g] = err;
+      if (p.errors && j == kTeam - 1 && live) p.errors[static_cast<int64_t>(k) * p.G + g] = p.errors_unrounded ? y : err;
       if (k == 0 || err < best_err) {
         best_err = err;
         best_k = k;
@@ -307,6 +308,107 @@ __global__ __launch_bounds__(256) void pow_table_kernel(uint16_t* table, double 
     r = static_cast<float>(pow(static_cast<double>(a), degree));
   }
   table[i] = Storage<ST>::store(r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Error of one given candidate: out[g] = sum_i pow(|a[g][i] - b[g][i]|, degree), the difference, magnitude and power
+// each rounded to the storage type, accumulated in float32 in the order of the torch CPU backend's contiguous
+// last-dimension sum (8 float lanes, four interleaved accumulators, 16-row cascade; 16-bit inputs folded pairwise)
+// and left UNROUNDED so the caller can round it (per group) or add groups up first (per channel group / per tensor).
+// ---------------------------------------------------------------------------------------------
+struct GroupErrorParams {
+  const void* a;
+  const void* b;
+  int64_t G, S;
+  float degree;
+  const uint16_t* table;
+  int32_t pow_mode;
+  float* out;
+};
+
+template <int ST>
+__global__ __launch_bounds__(256) void group_error_kernel(const GroupErrorParams p) {
+  using St = Storage<ST>;
+  using elem_t = typename St::elem_t;
+  constexpr bool PAIR = ST != DCQ_F32;
+  constexpr int kPerLoad = PAIR ? 2 * kTeam : kTeam;
+  const int j = threadIdx.x & (kTeam - 1);
+  const elem_t* a = static_cast<const elem_t*>(p.a);
+  const elem_t* b = static_cast<const elem_t*>(p.b);
+  const int64_t teams = static_cast<int64_t>(gridDim.x) * (256 / kTeam);
+  // whole waves iterate together: the trip count depends on the wave's first group only
+  for (int64_t g0 = static_cast<int64_t>(blockIdx.x) * (256 / kTeam); g0 < p.G; g0 += teams) {
+    const int64_t g = g0 + threadIdx.x / kTeam;
+    const bool live = g < p.G;
+    const elem_t* ag = a + (live ? g : 0) * p.S;
+    const elem_t* bg = b + (live ? g : 0) * p.S;
+    auto term = [&](int64_t i) -> float {
+      const float d = St::load(ag[i]) - St::load(bg[i]);
+      if (ST == DCQ_F32) {
+        const float m = fabsf(d);
+        return p.pow_mode == kPowSquare ? m * m : powf(m, p.degree);
+      }
+      const uint16_t eb = to_bits16<ST>(d) & 0x7fffu;
+      if (p.pow_mode == kPowTable) return from_bits16<ST>(p.table[eb]);
+      const float m = from_bits16<ST>(eb);
+      return from_bits16<ST>(to_bits16<ST>(m * m));
+    };
+    auto load = [&](int64_t m) -> float {
+      return PAIR ? term(m * kPerLoad + j) + term(m * kPerLoad + kTeam + j) : term(m * kPerLoad + j);
+    };
+    float tot = 0.0f;
+    if (p.S < kPerLoad) {
+      if (j == 0) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int64_t n4 = p.S / 4;
+        for (int64_t i = 0; i < n4; ++i)
+          for (int k = 0; k < 4; ++k) acc[k] = acc[k] + term(4 * i + k);
+        for (int64_t i = n4 * 4; i < p.S; ++i) acc[0] = acc[0] + term(i);
+        tot = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+      }
+    } else {
+      const int64_t nv = p.S / kPerLoad, rows = nv / 4;
+      float acc[4][4];
+#pragma unroll
+      for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[l][k] = 0.0f;
+      int64_t i = 0;
+      while (i + 16 <= rows) {
+        for (int t = 0; t < 16; ++t, ++i) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[0][k] = acc[0][k] + load(4 * i + k);
+        }
+        bool go = true;
+#pragma unroll
+        for (int l = 1; l < 4; ++l) {
+          if (go) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              acc[l][k] = acc[l][k] + acc[l - 1][k];
+              acc[l - 1][k] = 0.0f;
+            }
+            if ((i & (static_cast<int64_t>(15) << (4 * l))) != 0) go = false;
+          }
+        }
+      }
+      for (; i < rows; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[0][k] = acc[0][k] + load(4 * i + k);
+      }
+#pragma unroll
+      for (int l = 1; l < 4; ++l)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[0][k] = acc[0][k] + acc[l][k];
+      for (int64_t m = rows * 4; m < nv; ++m) acc[0][0] = acc[0][0] + load(m);
+      const float part = ((acc[0][0] + acc[0][1]) + acc[0][2]) + acc[0][3];
+      if (j == 0)
+        for (int64_t e = nv * kPerLoad; e < p.S; ++e) tot = tot + term(e);
+#pragma unroll
+      for (int t = 0; t < kTeam; ++t) tot = tot + __shfl(part, t, kTeam);  // meaningful in lane 0 (the tail's owner)
+    }
+    if (live && j == 0) p.out[g] = tot;
+  }
 }
 
 static double round_degree_to_storage(double degree, int storage) {
@@ -414,7 +516,7 @@ int dcq_pow_table(int32_t storage, double degree, uint16_t* table, dcq_stream_t 
 int dcq_range_search_groups(const dcq_step* step, const void* w, int32_t storage, int64_t G, int64_t S,
                             const float* ratios, int32_t K, double degree, const uint16_t* pow_table, float* best_max,
                             float* best_min, float* best_ratio, float* best_error, float* errors,
-                            dcq_stream_t stream) {
+                            int32_t errors_unrounded, dcq_stream_t stream) {
   DCQ_REQUIRE(step != nullptr, DCQ_ERR_ARGUMENT, "step is NULL");
   DCQ_REQUIRE(step->tensor.kind == DCQ_ROUND_INT || step->tensor.kind == DCQ_ROUND_CODEBOOK, DCQ_ERR_UNSUPPORTED,
               "tensor dtype must be an integer or a codebook type");
@@ -440,6 +542,7 @@ int dcq_range_search_groups(const dcq_step* step, const void* w, int32_t storage
   p.best_ratio = best_ratio;
   p.best_error = best_error;
   p.errors = errors;
+  p.errors_unrounded = errors_unrounded;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (storage == DCQ_F32) {
     p.degree = static_cast<float>(degree);
@@ -453,6 +556,40 @@ int dcq_range_search_groups(const dcq_step* step, const void* w, int32_t storage
   DCQ_REQUIRE(pow_table != nullptr, DCQ_ERR_ARGUMENT, "pow_table is NULL (build it with dcq_pow_table)");
   DCQ_REQUIRE((reinterpret_cast<uintptr_t>(pow_table) & 15u) == 0, DCQ_ERR_ARGUMENT, "pow_table must be 16-byte aligned");
   return storage == DCQ_BF16 ? search_size<DCQ_BF16, kPowTable>(p, s) : search_size<DCQ_F16, kPowTable>(p, s);
+}
+
+int dcq_group_error(const void* a, const void* b, int32_t storage, int64_t G, int64_t S, double degree,
+                    const uint16_t* pow_table, float* out, dcq_stream_t stream) {
+  DCQ_REQUIRE(G >= 0 && S > 0 && S <= (int64_t(1) << 24), DCQ_ERR_ARGUMENT, "bad sizes G=%lld S=%lld", (long long)G,
+              (long long)S);
+  if (G == 0) return DCQ_OK;
+  DCQ_REQUIRE(a && b && out, DCQ_ERR_ARGUMENT, "NULL buffer");
+  GroupErrorParams p{};
+  p.a = a;
+  p.b = b;
+  p.G = G;
+  p.S = S;
+  p.out = out;
+  p.table = pow_table;
+  int64_t blocks = (G + 31) / 32;
+  if (blocks > 65536) blocks = 65536;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (storage == DCQ_F32) {
+    p.degree = static_cast<float>(degree);
+    p.pow_mode = p.degree == 2.0f ? kPowSquare : kPowFloat;
+    hipLaunchKernelGGL(group_error_kernel<DCQ_F32>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+  } else {
+    DCQ_REQUIRE(storage == DCQ_F16 || storage == DCQ_BF16, DCQ_ERR_ARGUMENT, "bad storage %d", storage);
+    p.pow_mode = round_degree_to_storage(degree, storage) == 2.0 ? kPowSquare : kPowTable;
+    DCQ_REQUIRE(p.pow_mode != kPowTable || pow_table, DCQ_ERR_ARGUMENT, "pow_table is NULL (build it with dcq_pow_table)");
+    if (storage == DCQ_BF16) {
+      hipLaunchKernelGGL(group_error_kernel<DCQ_BF16>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+    } else {
+      hipLaunchKernelGGL(group_error_kernel<DCQ_F16>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+    }
+  }
+  DCQ_LAUNCH_CHECK("group_error_kernel launch");
+  return DCQ_OK;
 }
 
 }  // extern "C"

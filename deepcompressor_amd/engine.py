@@ -221,6 +221,7 @@ def prescale_groups(x: torch.Tensor, outer: torch.Tensor, lo: float, hi: float) 
     """clamp(x[g] / outer[g], lo, hi) as float32 [G][S]."""
     _require_gpu(x)
     G, S = x.shape
+    assert outer.numel() == G and outer.dtype == torch.float32 and outer.is_contiguous(), "one divisor per group"
     out = torch.empty((G, S), dtype=torch.float32, device=x.device)
     check(lib().dcq_prescale_groups(ptr(x), storage_of(x.dtype), G, S, ptr(outer), lo, hi, ptr(out),
                                     stream_of(x.device)), "dcq_prescale_groups")
@@ -251,8 +252,10 @@ def pow_table(device: torch.device, dtype: torch.dtype, degree: float) -> torch.
     return _pow_tables[key]
 
 
-def range_search_groups(step: Step, w: torch.Tensor, ratios: list[float], degree: float, *, want_errors=False):
-    """w[G][S] -> dict(max, min | None, ratio, error[, errors[K][G]]) of float32 tensors."""
+def range_search_groups(step: Step, w: torch.Tensor, ratios: list[float], degree: float, *, want_errors=False,
+                        unrounded_errors=False):
+    """w[G][S] -> dict(max, min | None, ratio, error[, errors[K][G]]) of float32 tensors.  ``errors`` holds the
+    per-candidate group errors rounded to the weight dtype, or the float32 sums before that rounding."""
     _require_gpu(w)
     G, S = w.shape
     dev = w.device
@@ -263,8 +266,22 @@ def range_search_groups(step: Step, w: torch.Tensor, ratios: list[float], degree
     table = pow_table(dev, w.dtype, degree) if w.dtype != torch.float32 else None
     check(lib().dcq_range_search_groups(C.byref(step), ptr(w), storage_of(w.dtype), G, S, ptr(r), len(ratios),
                                         float(degree), ptr(table), ptr(out["max"]), ptr(out["min"]),
-                                        ptr(out["ratio"]), ptr(out["error"]), ptr(errors), stream_of(dev)),
+                                        ptr(out["ratio"]), ptr(out["error"]), ptr(errors),
+                                        1 if unrounded_errors else 0, stream_of(dev)),
           "dcq_range_search_groups")
     if want_errors:
         out["errors"] = errors
+    return out
+
+
+def group_error(a: torch.Tensor, b: torch.Tensor, degree: float) -> torch.Tensor:
+    """a, b [G][S] of one dtype -> float32 [G]: sum over each group of |a - b|^degree evaluated in that dtype,
+    accumulated in float32 and not rounded back."""
+    _require_gpu(a)
+    assert a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+    G, S = a.shape
+    out = _f32(G, a.device)
+    table = pow_table(a.device, a.dtype, degree) if a.dtype != torch.float32 else None
+    check(lib().dcq_group_error(ptr(a), ptr(b), storage_of(a.dtype), G, S, float(degree), ptr(table), ptr(out),
+                                stream_of(a.device)), "dcq_group_error")
     return out

@@ -178,15 +178,25 @@ int dcq_dequantize_groups(const dcq_step* step, const float* codes, int64_t G, i
  * fake-quantize with that static range, error = sum over the group of |Q(w) - w|^degree evaluated in
  * the weight's storage type in the summation order of the torch CPU backend, keep the first strictly
  * smallest.  Outputs [G]: best_max, best_min (NULL without zero point), best_ratio (float32 of the
- * ratio), best_error (storage type, as float32 values); errors (optional, [K][G] float32 values).
+ * ratio), best_error (storage type, as float32 values); errors (optional, [K][G] float32 values: rounded to
+ * the storage type as the reference's per-group error is, or, with errors_unrounded, the float32 sums before
+ * that rounding, for callers that add groups up -- ChannelGroup / Layer granularity, calib/search.py:783-787).
  * S must be a multiple of 16 (16-bit storage) or 8 (float32) and at most 512.
+ *
+ * dcq_group_error: the error of ONE given candidate, for searches the fused kernel does not cover (progressive
+ * steps, multi-level scales, groups longer than 512): out[g] = sum_i pow(|a[g][i] - b[g][i]|, degree) over
+ * contiguous groups, difference / magnitude / power rounded to the storage type and summed in float32 in the order
+ * of the torch CPU backend's contiguous last-dimension sum, left unrounded (calib/search.py:779-787).
  * ------------------------------------------------------------------------------------------- */
 int dcq_pow_table(int32_t storage, double degree, uint16_t* table, dcq_stream_t stream);
 
 int dcq_range_search_groups(const dcq_step* step, const void* w, int32_t storage, int64_t G, int64_t S,
                             const float* ratios, int32_t K, double degree, const uint16_t* pow_table,
                             float* best_max, float* best_min, float* best_ratio, float* best_error, float* errors,
-                            dcq_stream_t stream);
+                            int32_t errors_unrounded, dcq_stream_t stream);
+
+int dcq_group_error(const void* a, const void* b, int32_t storage, int64_t G, int64_t S, double degree,
+                    const uint16_t* pow_table, float* out, dcq_stream_t stream);
 
 /* Self-test hook (no reference counterpart): evaluates the kernels' division-by-group-scale routine
  * (fast[i]; used_fast[i] says whether the reciprocal path or the plain division was taken) next to the

@@ -543,12 +543,97 @@ def gen_lowrank(ref) -> None:
     with open(os.path.join(OUT, "lowrank.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
+RANGE_WIDE_EXTRA_CASES = {
+    # groups longer than 512 values: per-channel rows of 2048
+    "sint4_gchn_long": dict(dtype="sint4", zero=None, groups=((1, -1),), sdt=("f16",), shape=(16, 2048)),
+}
+
+
+def gen_range_wide(ref) -> None:
+    """Layer / ChannelGroup granularity, long groups, multi-level scales and the per-step search of progressive
+    quantizers (calib/range.py:302-474)."""
+    import torch.nn as nn
+    from deepcompressor.calib.config import (
+        DynamicRangeCalibConfig,
+        SearchBasedCalibGranularity,
+        SearchBasedCalibObjective,
+        SearchBasedCalibStrategy,
+    )
+    from deepcompressor.calib.range import DynamicRangeCalibrator, calibrate_dynamic_range
+    from deepcompressor.data.cache import TensorCache, TensorsCache
+    from deepcompressor.data.common import TensorType
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+
+    cases = dict(FAKE_QUANT_CASES, **RANGE_WIDE_EXTRA_CASES)
+    arrays, meta = {}, {}
+    records: list[dict] = []
+    orig_tell = DynamicRangeCalibrator._tell
+
+    def tell(self, error, _orig=orig_tell):
+        if not records or records[-1]["owner"] is not self:
+            records.append(dict(owner=self, errors=[]))
+        records[-1]["errors"].append(_np(error[0]).copy())
+        _orig(self, error)
+
+    DynamicRangeCalibrator._tell = tell
+    try:
+        plan = [
+            ("sint4_g128_f16s", "bf16", 2.4, 100, "Layer"), ("uint4_post_g128_f16s", "f16", 2, 80, "Layer"),
+            ("sint4_g128_f16s", "f32", 2, 40, "Layer"), ("sint4_g128_f16s", "bf16", 2.4, 100, "ChannelGroup"),
+            ("sint4_gchn_long", "bf16", 2.4, 40, "Group"), ("sint4_gchn_long", "f16", 2, 40, "Group"),
+            ("sint4_gchn_g32_s8", "bf16", 2.4, 40, "Group"), ("nvfp4_g16", "bf16", 2, 40, "Group"),
+            ("sint4_2x64", "bf16", 2, 40, "Group"),
+            ("qoq_g128", "bf16", 2, 40, "Group"), ("qoq_g128", "f16", 2.4, 40, "Group"),
+            ("qoq_g128_pre", "bf16", 2, 40, "Group"),
+        ]
+        for cname, dt, degree, grids, gran in plan:
+            case = cases[cname]
+            w = _mk_input(case["shape"], dt, seed=2000 + len(cname) + len(dt))
+            q = _build_quantizer(ref, case)
+            cfg = DynamicRangeCalibConfig(
+                degree=degree, objective=SearchBasedCalibObjective.TensorError,
+                strategy=SearchBasedCalibStrategy.GridSearch, granularity=SearchBasedCalibGranularity[gran],
+                max_shrink=0.2, max_expand=1.0, num_grids=grids,
+            )
+            dummy = TensorsCache(TensorCache([torch.zeros(1, 8, w.shape[-1])], channels_dim=-1,
+                                             reshape=LinearReshapeFn()))
+            lin = nn.Linear(w.shape[1], w.shape[0], bias=False)
+            lin.weight = nn.Parameter(w, requires_grad=False)
+            tag = f"{cname}|{dt}|d{degree}|g{grids}|{gran}"
+            records.clear()
+            raised = None
+            try:
+                ranges = calibrate_dynamic_range(TensorType.Weights, cfg, True, q, [lin], dummy, eval_inputs=dummy)
+            except (RuntimeError, ValueError) as exc:  # the reference's own failure is part of the record
+                raised, ranges = str(exc).splitlines()[0][:200], ()
+            arrays[f"{tag}|x"] = _np(w)
+            arrays[f"{tag}|ratios"] = np.asarray([r for it in cfg.get_ratios() for r in it], dtype=np.float64)
+            for step, (rng, rec) in enumerate(zip(ranges, records)):
+                arrays[f"{tag}|s{step}|max"] = _np(rng.max)
+                if rng.min is not None:
+                    arrays[f"{tag}|s{step}|min"] = _np(rng.min)
+                arrays[f"{tag}|s{step}|ratio"] = _np(rec["owner"].best_range.ratio)
+                arrays[f"{tag}|s{step}|best_error"] = _np(rec["owner"].best_error)
+                arrays[f"{tag}|s{step}|errors"] = np.stack(rec["errors"])
+            if raised is not None and records:
+                arrays[f"{tag}|s0|errors"] = np.stack(records[0]["errors"])  # candidates scored before the failure
+            meta[tag] = dict(case=cname, in_dtype=dt, degree=degree, num_grids=grids, granularity=gran,
+                             num_steps=len(ranges), reference_raised=raised,
+                             codebook_via_restatement="fp" in case["dtype"] or any(
+                                 isinstance(x, str) and x.startswith("sfp") for x in case["sdt"]))
+    finally:
+        DynamicRangeCalibrator._tell = orig_tell
+    np.savez_compressed(os.path.join(OUT, "range_wide.npz"), **arrays)
+    with open(os.path.join(OUT, "range_wide.json"), "w") as f:
+        json.dump(dict(cases={k: {kk: (list(vv) if kk == "shape" else vv) for kk, vv in v.items()}
+                              for k, v in RANGE_WIDE_EXTRA_CASES.items()}, entries=meta), f, indent=1)
+
 
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "tables", "gptq", "rotate", "smooth", "lowrank"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "tables", "gptq", "rotate", "smooth", "lowrank"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)

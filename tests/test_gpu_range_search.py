@@ -37,7 +37,7 @@ def test_pow_table_exhaustive(dt, end, degree):
     assert not bad.any(), f"{int(bad.sum())} entries differ, first {int(np.flatnonzero(bad)[0])}"
 
 
-@pytest.mark.parametrize("tag", sorted(t for t in RS.meta if "gchn" not in t))
+@pytest.mark.parametrize("tag", sorted(RS.meta))
 def test_range_search_golden(tag):
     m = RS.meta[tag]
     case = FQ.meta["cases"][m["case"]]
