@@ -79,6 +79,7 @@ _SIGNATURES = {
     "dcq_range_search_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _i32, _d, _p, _p, _p, _p, _p, _p, _i32,
                                 _p],
     "dcq_group_error": [_p, _p, _i32, _i64, _i64, _d, _p, _p, _p],
+    "dcq_product_error": [_p, _p, _i32, _i64, _i64, _d, _i32, _p, _p],
 }
 _lib = None
 

@@ -8,8 +8,10 @@ keeps the best (tell).  Two device paths produce the same result here:
   takes the per-group winners straight from the kernel, ChannelGroup / Layer add the per-candidate group sums
   up over rows / the whole tensor first;
 * general -- anything else the weight search covers (a step of a progressive quantizer with the previous
-  steps' scale, multi-level scales, long or non-contiguous groups): the ask/tell loop itself, each candidate
-  fake-quantized by the HIP quantizer and scored by ``dcq_group_error``.
+  steps' scale, multi-level scales, long or non-contiguous groups, and the ProductsError / OutputsError
+  objectives): the ask/tell loop itself, each candidate fake-quantized by the HIP quantizer and scored by
+  ``dcq_group_error`` (the weight itself), ``dcq_product_error`` over the per-group partial products x @ w
+  (AWQ-style clipping search) or over the evaluation module's outputs.
 """
 
 from __future__ import annotations
@@ -94,21 +96,51 @@ class DynamicRangeCalibrator:
         return raw.double().sum(dim=dims).view(*raw.shape[:lead], *self.error_shape).to(dtype)
 
     # ---- entry -------------------------------------------------------------------------------------------------
-    def calibrate(self, x_wgts: list[nn.Parameter] | None = None, *, record_errors: bool = False,
-                  **unused) -> DynamicRange:
-        """Run the whole grid search; extra reference keyword arguments (eval_inputs, modules...) are accepted
-        and unused by the tensor-error objective."""
+    def _resolve_objective(self, eval_module) -> None:
+        """calib/search.py:361-414: OutputsError on a single linear / conv below Layer granularity is scored on
+        partial products; any other OutputsError is one scalar per candidate."""
+        self.objective, self.granularity = self.config.objective, self.config.granularity
+        if self.objective == SearchBasedCalibObjective.OutputsError:
+            if (isinstance(eval_module, (nn.Linear, nn.Conv2d))
+                    and self.granularity.value < SearchBasedCalibGranularity.Layer.value):
+                self.objective = SearchBasedCalibObjective.ProductsError
+            else:
+                self.granularity = SearchBasedCalibGranularity.Layer
+
+    @torch.inference_mode()
+    def calibrate(self, x_wgts: list[nn.Parameter] | None = None, *, x_acts: TensorsCache | None = None,
+                  x_mods: list[nn.Module] | None = None, eval_inputs: TensorsCache | None = None,
+                  eval_module: nn.Module | None = None, eval_kwargs: dict[str, tp.Any] | None = None,
+                  orig_x_wgts: list[tuple[nn.Parameter, torch.Tensor]] | None = None,
+                  orig_x_acts: TensorsCache | None = None, orig_eval_inputs: TensorsCache | None = None,
+                  record_errors: bool = False, **unused) -> DynamicRange:
+        """Run the whole grid search (SearchBasedCalibrator.calibrate, calib/search.py:532-684, weights only)."""
         if self.tensor_type != TensorType.Weights:
             raise self._unsupported(f"tensor type {self.tensor_type.name}")
-        if self.objective != SearchBasedCalibObjective.TensorError:
-            raise self._unsupported(f"objective {self.objective.name}")
         if not self.is_clamp_based():
             raise self._unsupported("allow_scale on a non-static tensor")
         assert x_wgts is not None and len(x_wgts) == 1, "The weight should be a single tensor."
-        w = x_wgts[0].detach().data
+        self._resolve_objective(eval_module)
+        param = x_wgts[0]
+        w = param.detach().data
         self._set_shapes(w.shape)
         q = self.quantizer
         info = q.update(w.shape, default_dtype=w.dtype)  # the search fake-quantizes with default_dtype = w.dtype
+        if self.objective == SearchBasedCalibObjective.ProductsError:
+            x_acts = x_acts or eval_inputs
+            assert x_acts is not None, "x_acts should not be None when objective is ProductsError"
+            self.path = "general"
+            self._calibrate_general(w, record_errors, self._products_scorer(w, x_acts, orig_x_wgts,
+                                                                            orig_x_acts or orig_eval_inputs))
+            return self.get_best()
+        if self.objective == SearchBasedCalibObjective.OutputsError:
+            assert eval_inputs is not None, "eval_inputs should not be None when objective is OutputsError"
+            assert eval_module is not None, "eval_module should not be None when OutputsError"
+            assert isinstance(param, nn.Parameter), "wgts should be a list of nn.Parameter"
+            self.path = "general"
+            self._calibrate_general(w, record_errors, self._outputs_scorer(
+                param, eval_inputs, eval_module, eval_kwargs or {}, orig_x_wgts, orig_eval_inputs))
+            return self.get_best()
         group_size = 1
         for s in self.view_shape[1::2]:
             group_size *= s
@@ -120,7 +152,7 @@ class DynamicRangeCalibrator:
         if fused:
             self._calibrate_fused(w, info.steps[0], record_errors)
         else:
-            self._calibrate_general(w, record_errors)
+            self._calibrate_general(w, record_errors, self._tensor_scorer(w))
         return self.get_best()
 
     # ---- fused path --------------------------------------------------------------------------------------------
@@ -175,27 +207,123 @@ class DynamicRangeCalibrator:
             tensor = tensor.view(self.pre_view_shape).mul_(self.pre_scale).to(dtype)
         return tensor.view(shape)
 
-    def _calibrate_general(self, w: torch.Tensor, record_errors: bool) -> None:
+    def _calibrate_general(self, w: torch.Tensor, record_errors: bool, scorer=None) -> None:
         view = self.view_shape
         zd = q_zero_domain(self.quantizer)
         is_fp = self.quantizer.config.quant_dtype.is_float_point
+        scorer = scorer or self._tensor_scorer(w)
         t = self._preprocess_with_pre_scale(w) if self.pre_scale is not None else w
         self.base_range = DynamicRange.construct(t.view(view).to(self.develop_dtype), zero_domain=zd, is_float_point=is_fp)
         del t
-        b2d, _ = engine.canonical_groups(w, view)
         self.best_range, self.best_error = DynamicRange(), None
         history = []
         for iteration in self.ratios:
             for ratio in iteration:
                 candidate = self.base_range.scale(ratio=ratio, zero_domain=zd, is_float_point=is_fp)
-                a2d, _ = engine.canonical_groups(self._process_wxy(w, candidate), view)
-                raw = engine.group_error(a2d, b2d, float(self.config.degree)).view(view[::2])
-                error = self._reduce(raw, w.dtype)
+                error = scorer(self._process_wxy(w, candidate))
                 if record_errors:
                     history.append(error.clone())
                 self._tell_general(error, candidate, ratio, w.device)
         if record_errors:
             self.candidate_errors = torch.stack(history)
+
+    # ---- what a candidate is scored on ------------------------------------------------------------------------
+    def _tensor_scorer(self, w: torch.Tensor):
+        """TensorError (calib/search.py:776-790): |Q(w) - w|^degree summed per group in the weight's dtype."""
+        view = self.view_shape
+        b2d, _ = engine.canonical_groups(w, view)
+
+        def score(qw: torch.Tensor) -> torch.Tensor:
+            a2d, _ = engine.canonical_groups(qw, view)
+            return self._reduce(engine.group_error(a2d, b2d, float(self.config.degree)).view(view[::2]), w.dtype)
+
+        return score
+
+    def _parse_ipts(self, ipts: TensorsCache | None) -> TensorsCache | None:
+        """calib/search.py:254-285."""
+        if ipts is None:
+            return None
+        products = self.objective == SearchBasedCalibObjective.ProductsError
+        batch = self.config.element_batch_size if products else self.config.sample_batch_size
+        size = self.config.element_size if products else self.config.sample_size
+        return TensorsCache({key: ipt.repartition(max_batch_size=batch, max_size=size, standardize=products,
+                                                  reshape=True) for key, ipt in ipts.items()})
+
+    def _products_scorer(self, w: torch.Tensor, x_acts: TensorsCache, orig_x_wgts, orig_x_acts):
+        """ProductsError (calib/search.py:697-745, 791-816).  Per input batch x[n, C] the reference multiplies every
+        quantization group on its own, y[r, cg, n] = sum_i x[n, cg*g + i] * w[r, cg*g + i], in the weight's dtype
+        (a broadcast matmul over (R, C/g) tiny products); here that is one batched GEMM over the C/g column groups.
+        Error per (r, cg) = sum_n float32(dtype(y - y0))^degree, batches added up in float32."""
+        view = self.view_shape
+        if len(view) != 4 or view[1] != 1:
+            raise self._unsupported("ProductsError for weights that are not 2-D with (1, g) groups")
+        R, _, CG, g = view
+        assert x_acts.num_tensors == 1, "a linear takes one input"
+        ipts, orig_ipts = self._parse_ipts(x_acts), self._parse_ipts(orig_x_acts)
+        dev, dt = w.device, w.dtype
+
+        def grouped(x: torch.Tensor) -> torch.Tensor:  # [n, C] -> [CG, g, n]
+            return x.to(device=dev, dtype=dt).view(-1, CG, g).permute(1, 2, 0).contiguous()
+
+        def products(xg: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:  # -> [CG * R, n]
+            return torch.bmm(weight.view(R, CG, g).transpose(0, 1), xg).view(CG * R, -1)
+
+        batches = [grouped(ipts.front().reshape(x)) for x in ipts.front().data]
+        orig_w = orig_x_wgts[0][1].to(dev) if orig_x_wgts is not None else w
+        orig_batches = batches if orig_ipts is None else [grouped(orig_ipts.front().reshape(x))
+                                                          for x in orig_ipts.front().data]
+        base = [products(xg, orig_w) for xg in orig_batches]
+        degree = float(self.config.degree)
+
+        def score(qw: torch.Tensor) -> torch.Tensor:
+            total = None
+            for xg, y0 in zip(batches, base):
+                total = engine.product_error(products(xg, qw), y0, degree, out=total)
+            per_group = total.view(CG, R).t()
+            if self.granularity == SearchBasedCalibGranularity.Group:
+                return per_group.contiguous()
+            return per_group.double().sum(dim=0).to(torch.float32)  # ChannelGroup
+
+        return score
+
+    def _outputs_scorer(self, param: nn.Parameter, eval_inputs: TensorsCache, eval_module: nn.Module,
+                        eval_kwargs: dict, orig_x_wgts, orig_eval_inputs):
+        """OutputsError (calib/search.py:746-765, 817-832): the evaluation module's outputs with the candidate
+        weight in place against its outputs with the original weight; one scalar per candidate."""
+        ipts, orig_ipts = self._parse_ipts(eval_inputs), self._parse_ipts(orig_eval_inputs)
+        degree = float(self.config.degree)
+
+        def forward(cache: TensorsCache, index: int) -> torch.Tensor:
+            ipt = cache.extract(index, eval_kwargs)
+            y = eval_module(*ipt.args, **ipt.kwargs)
+            y = y[0] if not isinstance(y, torch.Tensor) else y
+            assert isinstance(y, torch.Tensor), "eval_mod should return a tensor"
+            return y.contiguous().view(-1, y.shape[-1])
+
+        saved = []
+        if orig_x_wgts is not None:
+            saved = [(p, p.data) for p, _ in orig_x_wgts]
+            for p, ow in orig_x_wgts:
+                p.data = ow.to(device=p.data.device)
+        ref = orig_ipts or ipts
+        base = [forward(ref, i) for i in range(len(ref.front().data))]
+        for p, ow in saved:
+            p.data = ow
+
+        def score(qw: torch.Tensor) -> torch.Tensor:
+            kept = param.data
+            param.data = qw
+            try:
+                rows = None
+                for i, y0 in enumerate(base):
+                    y = forward(ipts, i)
+                    rows = engine.product_error(y, y0, degree) if rows is None else \
+                        torch.cat([rows, engine.product_error(y, y0, degree)])
+            finally:
+                param.data = kept
+            return rows.double().sum().to(torch.float32).view(1)
+
+        return score
 
     def _tell_general(self, error: torch.Tensor, candidate: DynamicRange, ratio: float, device) -> None:
         """calib/range.py:183-221.  Per channel group the reference's own update cannot run (it reshapes the mask
@@ -258,9 +386,18 @@ def calibrate_dynamic_range(tensor_type: TensorType, config: DynamicRangeCalibCo
         weights = [m.weight for m in modules if hasattr(m, "weight")]
     if tensor_type == TensorType.Weights:
         assert len(modules) == 1 and len(weights) == 1, "only one module / weight per weight-range calibration"
+        if eval_module is None:
+            eval_module = modules[0]
+            if eval_inputs is None:
+                eval_inputs = activations
+        else:
+            assert eval_inputs is not None, "eval_inputs is required when eval_module is provided"
+    search_args = dict(x_acts=activations, x_mods=list(modules), eval_inputs=eval_inputs, eval_module=eval_module,
+                       eval_kwargs=eval_kwargs, orig_x_wgts=orig_weights, orig_x_acts=orig_activations,
+                       orig_eval_inputs=orig_eval_inputs)
     if num_steps == 1:
         calibrator = DynamicRangeCalibrator(tensor_type=tensor_type, config=config, static=static, quantizer=quantizer)
-        return (calibrator.calibrate(x_wgts=list(weights)),)
+        return (calibrator.calibrate(x_wgts=list(weights), **search_args),)
     # progressive quantizer: one calibrator per step, each seeing the tensor divided by the scales found so far
     if tensor_type != TensorType.Weights:
         raise NotImplementedError("progressive range search is implemented for weights only")
@@ -277,7 +414,7 @@ def calibrate_dynamic_range(tensor_type: TensorType, config: DynamicRangeCalibCo
                                    default_dtype=quantizer.default_dtype, develop_dtype=quantizer.develop_dtype)
         step_range = DynamicRangeCalibrator(tensor_type=tensor_type, config=config, static=static,
                                             quantizer=step_quantizer, pre_scale=quant_scale.data
-                                            ).calibrate(x_wgts=list(weights))
+                                            ).calibrate(x_wgts=list(weights), **search_args)
         dynamic_ranges.append(step_range)
         step_scale, _ = step_info.scale.quantize(tensor=develop_tensor.view(step_info.tensor_shape),
                                                  dynamic_range=step_range)

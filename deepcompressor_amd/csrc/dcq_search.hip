@@ -323,14 +323,17 @@ struct GroupErrorParams {
   float degree;
   const uint16_t* table;
   int32_t pow_mode;
+  int32_t accumulate;
   float* out;
 };
 
-template <int ST>
+// PRODUCTS: the operands are products x @ w in the storage type; their difference is rounded to that type, then
+// widened to float32 and raised to the degree there with its sign (calib/search.py:803-810); plain float32 sum order.
+template <int ST, bool PRODUCTS>
 __global__ __launch_bounds__(256) void group_error_kernel(const GroupErrorParams p) {
   using St = Storage<ST>;
   using elem_t = typename St::elem_t;
-  constexpr bool PAIR = ST != DCQ_F32;
+  constexpr bool PAIR = ST != DCQ_F32 && !PRODUCTS;
   constexpr int kPerLoad = PAIR ? 2 * kTeam : kTeam;
   const int j = threadIdx.x & (kTeam - 1);
   const elem_t* a = static_cast<const elem_t*>(p.a);
@@ -344,6 +347,10 @@ __global__ __launch_bounds__(256) void group_error_kernel(const GroupErrorParams
     const elem_t* bg = b + (live ? g : 0) * p.S;
     auto term = [&](int64_t i) -> float {
       const float d = St::load(ag[i]) - St::load(bg[i]);
+      if (PRODUCTS) {
+        const float r = St::round(d);
+        return p.pow_mode == kPowSquare ? r * r : powf(r, p.degree);
+      }
       if (ST == DCQ_F32) {
         const float m = fabsf(d);
         return p.pow_mode == kPowSquare ? m * m : powf(m, p.degree);
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(256) void group_error_kernel(const GroupErrorParams
 #pragma unroll
       for (int t = 0; t < kTeam; ++t) tot = tot + __shfl(part, t, kTeam);  // meaningful in lane 0 (the tail's owner)
     }
-    if (live && j == 0) p.out[g] = tot;
+    if (live && j == 0) p.out[g] = p.accumulate ? p.out[g] + tot : tot;
   }
 }
 
@@ -577,18 +584,54 @@ int dcq_group_error(const void* a, const void* b, int32_t storage, int64_t G, in
   if (storage == DCQ_F32) {
     p.degree = static_cast<float>(degree);
     p.pow_mode = p.degree == 2.0f ? kPowSquare : kPowFloat;
-    hipLaunchKernelGGL(group_error_kernel<DCQ_F32>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((group_error_kernel<DCQ_F32, false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
   } else {
     DCQ_REQUIRE(storage == DCQ_F16 || storage == DCQ_BF16, DCQ_ERR_ARGUMENT, "bad storage %d", storage);
     p.pow_mode = round_degree_to_storage(degree, storage) == 2.0 ? kPowSquare : kPowTable;
     DCQ_REQUIRE(p.pow_mode != kPowTable || pow_table, DCQ_ERR_ARGUMENT, "pow_table is NULL (build it with dcq_pow_table)");
     if (storage == DCQ_BF16) {
-      hipLaunchKernelGGL(group_error_kernel<DCQ_BF16>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((group_error_kernel<DCQ_BF16, false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
     } else {
-      hipLaunchKernelGGL(group_error_kernel<DCQ_F16>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((group_error_kernel<DCQ_F16, false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
     }
   }
   DCQ_LAUNCH_CHECK("group_error_kernel launch");
+  return DCQ_OK;
+}
+
+int dcq_product_error(const void* y, const void* y0, int32_t storage, int64_t G, int64_t S, double degree,
+                      int32_t accumulate, float* out, dcq_stream_t stream) {
+  DCQ_REQUIRE(G >= 0 && S > 0 && S <= (int64_t(1) << 24), DCQ_ERR_ARGUMENT, "bad sizes G=%lld S=%lld", (long long)G,
+              (long long)S);
+  if (G == 0) return DCQ_OK;
+  DCQ_REQUIRE(y && y0 && out, DCQ_ERR_ARGUMENT, "NULL buffer");
+  GroupErrorParams p{};
+  p.a = y;
+  p.b = y0;
+  p.G = G;
+  p.S = S;
+  p.out = out;
+  p.accumulate = accumulate;
+  p.degree = static_cast<float>(degree);
+  p.pow_mode = p.degree == 2.0f ? kPowSquare : kPowFloat;
+  int64_t blocks = (G + 31) / 32;
+  if (blocks > 65536) blocks = 65536;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (storage) {
+    case DCQ_F32:
+      hipLaunchKernelGGL((group_error_kernel<DCQ_F32, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+      break;
+    case DCQ_F16:
+      hipLaunchKernelGGL((group_error_kernel<DCQ_F16, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+      break;
+    case DCQ_BF16:
+      hipLaunchKernelGGL((group_error_kernel<DCQ_BF16, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, p);
+      break;
+    default:
+      set_error("bad storage %d", storage);
+      return DCQ_ERR_ARGUMENT;
+  }
+  DCQ_LAUNCH_CHECK("group_error_kernel (products) launch");
   return DCQ_OK;
 }
 

@@ -285,3 +285,17 @@ def group_error(a: torch.Tensor, b: torch.Tensor, degree: float) -> torch.Tensor
     check(lib().dcq_group_error(ptr(a), ptr(b), storage_of(a.dtype), G, S, float(degree), ptr(table), ptr(out),
                                 stream_of(a.device)), "dcq_group_error")
     return out
+
+
+def product_error(y: torch.Tensor, y0: torch.Tensor, degree: float, out: torch.Tensor | None = None) -> torch.Tensor:
+    """y, y0 [G][S] of one dtype -> float32 [G]: sum_i float32(dtype(y - y0))^degree, added to ``out`` when given."""
+    _require_gpu(y)
+    assert y.shape == y0.shape and y.dtype == y0.dtype and y.is_contiguous() and y0.is_contiguous()
+    G, S = y.shape
+    accumulate = out is not None
+    if out is None:
+        out = _f32(G, y.device)
+    assert out.numel() == G and out.dtype == torch.float32 and out.is_contiguous()
+    check(lib().dcq_product_error(ptr(y), ptr(y0), storage_of(y.dtype), G, S, float(degree), int(accumulate), ptr(out),
+                                  stream_of(y.device)), "dcq_product_error")
+    return out

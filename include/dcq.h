@@ -198,6 +198,13 @@ int dcq_range_search_groups(const dcq_step* step, const void* w, int32_t storage
 int dcq_group_error(const void* a, const void* b, int32_t storage, int64_t G, int64_t S, double degree,
                     const uint16_t* pow_table, float* out, dcq_stream_t stream);
 
+/* Error of products / outputs for the ProductsError and OutputsError objectives (calib/search.py:803-810, 825-830):
+ * out[g] (+)= sum_i pow(float32(storage(y[g][i] - y0[g][i])), degree) -- the difference rounded to the operands'
+ * storage type, the power (with the difference's sign, as the reference has no abs here) and the sum in float32.
+ * `accumulate` adds to out, which is how the reference adds batches up. */
+int dcq_product_error(const void* y, const void* y0, int32_t storage, int64_t G, int64_t S, double degree,
+                      int32_t accumulate, float* out, dcq_stream_t stream);
+
 /* Self-test hook (no reference counterpart): evaluates the kernels' division-by-group-scale routine
  * (fast[i]; used_fast[i] says whether the reciprocal path or the plain division was taken) next to the
  * hardware's IEEE division (ref[i]) for n pairs (x[i], s[i]), so a test can assert bitwise equality. */

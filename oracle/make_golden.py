@@ -628,12 +628,103 @@ def gen_range_wide(ref) -> None:
         json.dump(dict(cases={k: {kk: (list(vv) if kk == "shape" else vv) for kk, vv in v.items()}
                               for k, v in RANGE_WIDE_EXTRA_CASES.items()}, entries=meta), f, indent=1)
 
+def gen_range_products(ref) -> None:
+    """Weight range search scored on products / outputs instead of the weight itself (calib/search.py:697-770,
+    791-832): the AWQ-style ProductsError, OutputsError on a linear (which the reference turns into ProductsError
+    below Layer granularity, calib/search.py:397-409) and OutputsError at Layer granularity."""
+    import torch.nn as nn
+    from deepcompressor.calib.config import (
+        DynamicRangeCalibConfig,
+        SearchBasedCalibGranularity,
+        SearchBasedCalibObjective,
+        SearchBasedCalibStrategy,
+    )
+    from deepcompressor.calib.range import DynamicRangeCalibrator, calibrate_dynamic_range
+    from deepcompressor.data.cache import TensorCache, TensorsCache
+    from deepcompressor.data.common import TensorType
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+
+    arrays, meta = {}, {}
+    records: list[dict] = []
+    orig_tell = DynamicRangeCalibrator._tell
+
+    def tell(self, error, _orig=orig_tell):
+        if not records or records[-1]["owner"] is not self:
+            records.append(dict(owner=self, errors=[]))
+        records[-1]["errors"].append(_np(error[0]).copy())
+        _orig(self, error)
+
+    DynamicRangeCalibrator._tell = tell
+    try:
+        plan = [
+            ("sint4_g128_f16s", "f32", 2, 20, "ProductsError", "Group", 16),
+            ("sint4_g128_f16s", "bf16", 2, 20, "ProductsError", "Group", 16),
+            ("uint4_post_g128_f16s", "f16", 2, 20, "OutputsError", "Group", -1),
+            ("uint4_post_g128_f16s", "f32", 2, 20, "OutputsError", "Group", -1),
+            ("sint4_g128_f16s", "f32", 2, 20, "ProductsError", "ChannelGroup", -1),
+            ("sint4_g128_f16s", "f32", 2, 20, "OutputsError", "Layer", -1),
+            ("sint4_g128_f16s", "bf16", 2, 20, "OutputsError", "Layer", -1),
+            ("uint4_pre_g128_f16s", "f32", 4, 10, "OutputsError", "Layer", -1),
+        ]
+        for cname, dt, degree, grids, objective, gran, ebatch in plan:
+            case = FAKE_QUANT_CASES[cname]
+            w = _mk_input(case["shape"], dt, seed=3000 + len(cname) + len(dt))
+            g = torch.Generator().manual_seed(77 + len(cname))
+            gains = torch.exp(torch.randn(w.shape[1], generator=g))
+            xs = [(torch.randn(2, 16, w.shape[1], generator=g) * gains).to(TORCH_DT[dt]) for _ in range(2)]
+            bias = (torch.randn(w.shape[0], generator=g) * 0.1).to(TORCH_DT[dt])
+            q = _build_quantizer(ref, case)
+            cfg = DynamicRangeCalibConfig(
+                degree=degree, objective=SearchBasedCalibObjective[objective],
+                strategy=SearchBasedCalibStrategy.GridSearch, granularity=SearchBasedCalibGranularity[gran],
+                max_shrink=0.8, max_expand=1.0, num_grids=grids, element_batch_size=ebatch,
+                element_size=-1, sample_batch_size=-1, sample_size=-1,
+            )
+            acts = TensorsCache(TensorCache([x.clone() for x in xs], channels_dim=-1, reshape=LinearReshapeFn(),
+                                            num_cached=2, num_total=2, num_samples=4))
+            lin = nn.Linear(w.shape[1], w.shape[0], bias=True).to(TORCH_DT[dt])
+            lin.weight = nn.Parameter(w.clone(), requires_grad=False)
+            lin.bias = nn.Parameter(bias, requires_grad=False)
+            tag = f"{cname}|{dt}|d{degree}|g{grids}|{objective}|{gran}|e{ebatch}"
+            records.clear()
+            raised = None
+            try:
+                with torch.inference_mode():
+                    ranges = calibrate_dynamic_range(TensorType.Weights, cfg, True, q, [lin], acts)
+            except (RuntimeError, ValueError) as exc:
+                raised, ranges = str(exc).splitlines()[0][:200], ()
+            assert torch.equal(lin.weight.data, w), "the search must leave the weight as it found it"
+            arrays[f"{tag}|w"] = _np(w)
+            arrays[f"{tag}|bias"] = _np(bias)
+            for i, x in enumerate(xs):
+                arrays[f"{tag}|x{i}"] = _np(x)
+            arrays[f"{tag}|ratios"] = np.asarray([r for it in cfg.get_ratios() for r in it], dtype=np.float64)
+            for step, (rng, rec) in enumerate(zip(ranges, records)):
+                arrays[f"{tag}|s{step}|max"] = _np(rng.max)
+                if rng.min is not None:
+                    arrays[f"{tag}|s{step}|min"] = _np(rng.min)
+                arrays[f"{tag}|s{step}|ratio"] = _np(rec["owner"].best_range.ratio)
+                arrays[f"{tag}|s{step}|best_error"] = _np(rec["owner"].best_error)
+                arrays[f"{tag}|s{step}|errors"] = np.stack(rec["errors"])
+            if raised is not None and records:
+                arrays[f"{tag}|s0|errors"] = np.stack(records[0]["errors"])
+            meta[tag] = dict(case=cname, in_dtype=dt, degree=degree, num_grids=grids, objective=objective,
+                             granularity=gran, element_batch_size=ebatch, num_steps=len(ranges),
+                             reference_raised=raised,
+                             resolved_objective=records[0]["owner"].objective.name if records else None,
+                             resolved_granularity=records[0]["owner"].granularity.name if records else None)
+    finally:
+        DynamicRangeCalibrator._tell = orig_tell
+    np.savez_compressed(os.path.join(OUT, "range_products.npz"), **arrays)
+    with open(os.path.join(OUT, "range_products.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
 
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "tables", "gptq", "rotate", "smooth", "lowrank"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "lowrank"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
