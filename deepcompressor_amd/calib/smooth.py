@@ -1,16 +1,17 @@
 """Smooth quantization (reference: deepcompressor/calib/smooth.py:34-1109).
 
-Same call surface as the reference for the weight-centric path: ``smooth_linear_modules`` with a given scale or a
-``SmoothLinearCalibrator`` search (Manual / GridSearch over (alpha, beta) x span pairs, scored on the outputs of
-an evaluation module, Layer granularity).  What runs where:
+Same call surface as the reference: ``smooth_linear_modules`` (weight-centric, x-w) and ``smooth_attention``
+(outputs-centric, query-key) with a given scale or a ``SmoothLinearCalibrator`` / ``SmoothAttentionCalibrator``
+search (Manual / GridSearch over (alpha, beta) x span pairs, scored on the outputs of an evaluation module, Layer
+granularity).  What runs where:
 
 * per-channel spans of activations and weights        -> ``dcq_channel_metric``   (one pass each, HBM-bound)
 * ``W * s`` / ``W / s`` / ``x / s`` / ``x * s`` (+ cast) -> ``dcq_scale_channels``   (one pass, fused cast)
 * fake quantization of the scaled tensors             -> the ``Quantizer`` kernels
 * the evaluation module's forward                     -> torch on the GPU (the module belongs to the caller)
 
-Not implemented (raise): query/key smoothing search (``SmoothAttentionCalibrator``), ProductsError / ChannelGroup
-scoring, the low-rank-aware candidate processing.
+Not implemented (raise): ProductsError / ChannelGroup scoring of smoothing candidates, the low-rank-aware
+candidate processing.
 """
 
 from __future__ import annotations
@@ -127,8 +128,9 @@ def _head_reduce(span: torch.Tensor, unique_heads: int, repeats: int, use_max: b
 
 
 class SmoothCalibrator:
-    """Search over smoothing scales for x-w products (``tensor_type`` Weights).  Ask / tell structure, candidate
-    order and tie rule follow the reference (smooth.py:149-714, search.py:63-837)."""
+    """Search over smoothing scales for x-w products (``tensor_type`` Weights) or y-x products such as query-key
+    (``tensor_type`` Outputs).  Ask / tell structure, candidate order and tie rule follow the reference
+    (smooth.py:149-714, search.py:63-1078)."""
 
     def __init__(self, tensor_type: TensorType, config: SmoothCalibConfig, w_quantizer: Quantizer | None,
                  x_quantizer: Quantizer | None, y_quantizer: Quantizer | None, num_heads: int = 1,
@@ -141,6 +143,8 @@ class SmoothCalibrator:
         self.needs_w_quant, self.needs_x_quant, self.needs_y_quant = map(enabled, (w_quantizer, x_quantizer, y_quantizer))
         self.needs_x_quant_for_wgts = config.allow_a_quant and self.needs_x_quant
         self.needs_w_quant_for_wgts = config.allow_b_quant and self.needs_w_quant
+        self.needs_x_quant_for_opts = config.allow_b_quant and self.needs_x_quant  # smooth.py:242-250
+        self.needs_y_quant_for_opts = config.allow_a_quant and self.needs_y_quant
         self.num_heads, self.num_head_repeats = num_heads, num_head_repeats
         self.with_rope = tensor_type != TensorType.Weights and with_rope
 
@@ -164,32 +168,61 @@ class SmoothCalibrator:
     def is_done(self) -> bool:
         return self.iter >= self.num_iters
 
-    def reset(self, *, x_wgts: list[torch.Tensor], x_acts: TensorsCache, **kwargs) -> None:
+    def reset(self, *, x_wgts: list[torch.Tensor], x_acts: TensorsCache, y_wgts: list[torch.Tensor] | None = None,
+              y_acts: TensorsCache | None = None, **kwargs) -> None:
+        """smooth.py:272-386."""
         self.iter = self.candidate_id = 0
         self._state_dict: list[tuple[nn.Parameter, torch.Tensor]] = []
         self._hooks: list = []
-        self.num_in_channels = x_wgts[0].shape[1]
+        wgts_centric = self.tensor_type == TensorType.Weights
+        self.num_in_channels = x_wgts[0].shape[1] if wgts_centric else x_wgts[0].shape[0]
         device = x_wgts[0].device
         grouped = self.num_heads > 1 and self.num_head_repeats > 1
         self.num_unique_heads = self.num_heads // self.num_head_repeats if grouped else 0
         assert x_acts.num_tensors == 1, f"Only one input is allowed, got {x_acts.num_tensors}"
         x_tensors = x_acts.front().get_standardized_data(reshape=False)
         assert all(x.shape[1] == self.num_in_channels for x in x_tensors)
-        assert all(w.shape[1] == self.num_in_channels for w in x_wgts)
 
-        def spans_of(tensors, group_shape, modes):
+        def rope_reduce(span, use_max):
+            # rotary embedding pairs channel i with i + head_dim / 2: both halves of a head share one span
+            span = span.view(self.num_heads, 2, -1)
+            span = span.amax(dim=1, keepdim=True) if use_max else span.mean(dim=1, keepdim=True)
+            return span.expand(self.num_heads, 2, -1).reshape(-1)
+
+        def spans_of(tensors, group_shape, modes, *, heads: str, rope: bool):
             out = {}
             for mode in modes:
                 span = get_smooth_span(tensors, group_shape=group_shape, span_mode=mode, device=device,
                                        dtype=self.develop_dtype)
                 if self.num_unique_heads > 0:
-                    span = _head_reduce(span, self.num_unique_heads, self.num_head_repeats, "Max" in mode.name)
+                    if heads == "reduce":
+                        span = _head_reduce(span, self.num_unique_heads, self.num_head_repeats, "Max" in mode.name)
+                    else:  # one span per key/value head, repeated for the query heads that share it
+                        span = span.view(self.num_unique_heads, 1, -1).expand(
+                            self.num_unique_heads, self.num_head_repeats, -1).reshape(-1)
+                if rope:
+                    span = rope_reduce(span, "Max" in mode.name)
                 out[mode] = span
             return out
 
-        x_spans = spans_of(x_tensors, self.x_group_shape, self.config.a_spans)
-        w_spans = spans_of([w.data for w in x_wgts], self.w_group_shape, self.config.b_spans)
-        self.span_pairs = [(x_spans[a], w_spans[b]) for a, b in self.config.spans]
+        rope = not wgts_centric and self.with_rope
+        x_spans = spans_of(x_tensors, self.x_group_shape, self.config.a_spans if wgts_centric else self.config.b_spans,
+                           heads="reduce", rope=rope)
+        if wgts_centric:
+            assert all(w.shape[1] == self.num_in_channels for w in x_wgts)
+            w_spans = spans_of([w.data for w in x_wgts], self.w_group_shape, self.config.b_spans, heads="reduce",
+                               rope=False)
+            self.span_pairs = [(x_spans[a], w_spans[b]) for a, b in self.config.spans]
+        else:
+            assert y_acts is not None and y_acts.num_tensors == 1, "Only one output source is allowed"
+            num_out_channels = (self.num_in_channels // self.num_head_repeats if self.num_unique_heads > 0
+                                else self.num_in_channels)
+            assert all(w.shape[0] == self.num_in_channels for w in x_wgts)
+            assert all(w.shape[0] == num_out_channels for w in y_wgts)
+            y_tensors = y_acts.front().get_standardized_data(reshape=False)
+            assert all(y.shape[1] == num_out_channels for y in y_tensors)
+            y_spans = spans_of(y_tensors, self.x_group_shape, self.config.a_spans, heads="expand", rope=rope)
+            self.span_pairs = [(y_spans[a], x_spans[b]) for a, b in self.config.spans]
         self.best_error: list[torch.Tensor] | None = None
         self.best_scale: torch.Tensor | None = None
         self.error_history: list[list[torch.Tensor]] = []  # every candidate's errors, in candidate order
@@ -252,6 +285,36 @@ class SmoothCalibrator:
         if self.needs_x_quant_for_wgts:
             self._hooks.append(self.x_quantizer.as_hook(func=self._process_x_in_xw, is_output=False).register(mods))
 
+    def _reduced_scale(self, scale: torch.Tensor) -> torch.Tensor:
+        """The scale of the key/value heads: the first of each group of query heads that share one."""
+        if self.num_unique_heads > 0:
+            return scale.view(self.num_unique_heads, self.num_head_repeats, -1)[:, 0, :].reshape(-1)
+        return scale
+
+    def _quantize_output(self, quantizer: Quantizer, t: torch.Tensor) -> torch.Tensor:
+        """smooth.py:532-572 with the OutputsError objective: the producing weights were already scaled, so the
+        tensor is only fake-quantized."""
+        return quantizer.quantize(t, channels_dim=quantizer.channels_dim, default_dtype=t.dtype,
+                                  develop_dtype=self.develop_dtype).data.view(t.shape)
+
+    def _process_opts_centric_mod(self, x_wgts: list[nn.Parameter], y_wgts: list[nn.Parameter],
+                                  x_mods: list[nn.Module], y_mods: list[nn.Module]) -> None:
+        """Candidate in place for a y-x product (smooth.py:627-653): the rows of the x producers are multiplied by
+        the scale, the rows of the y producers divided, and both products fake-quantized as they leave their
+        modules."""
+        for w in x_wgts:
+            self._state_dict.append((w, w.data))
+            w.data = scale_channels(w.detach().data, self.candidate, 0, divide=False)
+        for w in y_wgts:
+            self._state_dict.append((w, w.data))
+            w.data = scale_channels(w.detach().data, self._reduced_scale(self.candidate), 0, divide=True)
+        if self.needs_x_quant_for_opts:
+            self._hooks.append(self.x_quantizer.as_hook(lambda t: self._quantize_output(self.x_quantizer, t),
+                                                        is_output=True).register(x_mods))
+        if self.needs_y_quant_for_opts:
+            self._hooks.append(self.y_quantizer.as_hook(lambda t: self._quantize_output(self.y_quantizer, t),
+                                                        is_output=True).register(y_mods))
+
     def _recover_mod(self) -> None:
         for p, w in self._state_dict:
             p.data = w
@@ -273,22 +336,27 @@ class SmoothCalibrator:
                   x_mods: list[nn.Module] | None = None, eval_inputs: TensorsCache | None = None,
                   eval_module: nn.Module | None = None, eval_kwargs: dict[str, tp.Any] | None = None,
                   orig_x_wgts: list[tuple[nn.Parameter, torch.Tensor]] | None = None,
-                  orig_eval_inputs: TensorsCache | None = None, **kwargs) -> torch.Tensor:
-        if self.tensor_type != TensorType.Weights:
-            raise NotImplementedError("only the weight-centric (x-w) smoothing search is implemented")
+                  orig_eval_inputs: TensorsCache | None = None, y_wgts: list[nn.Parameter] | None = None,
+                  y_acts: TensorsCache | None = None, y_mods: list[nn.Module] | None = None,
+                  orig_y_wgts: list[tuple[nn.Parameter, torch.Tensor]] | None = None, **kwargs) -> torch.Tensor:
         assert all(isinstance(w, nn.Parameter) for w in x_wgts), "wgts should be a list of nn.Parameter"
         objective, granularity = self.config.objective, self.config.granularity
+        outputs_centric = self.tensor_type == TensorType.Outputs
+        if outputs_centric:  # search.py:363-366
+            objective, granularity = SearchBasedCalibObjective.OutputsError, SearchBasedCalibGranularity.Layer
         if objective == SearchBasedCalibObjective.OutputsError and not (
-                isinstance(eval_module, (nn.Linear, nn.Conv2d)) and granularity != SearchBasedCalibGranularity.Layer):
+                not outputs_centric and isinstance(eval_module, (nn.Linear, nn.Conv2d))
+                and granularity != SearchBasedCalibGranularity.Layer):
             granularity = SearchBasedCalibGranularity.Layer
         else:
             raise NotImplementedError(f"smoothing search with {objective.name} / {granularity.name} is not implemented")
+        self.objective, self.granularity = objective, granularity
         assert eval_inputs is not None, "eval_inputs should not be None when objective is OutputsError"
         assert eval_module is not None, "eval_module should not be None when OutputsError"
         x_acts = x_acts or eval_inputs
         eval_kwargs = eval_kwargs or {}
         eval_inputs, orig_eval_inputs = self._parse_inputs(eval_inputs), self._parse_inputs(orig_eval_inputs)
-        self.reset(x_wgts=x_wgts, x_acts=x_acts)
+        self.reset(x_wgts=x_wgts, x_acts=x_acts, y_wgts=y_wgts, y_acts=y_acts)
 
         def forward(cache: TensorsCache, index: int) -> torch.Tensor:
             ipt = cache.extract(index, eval_kwargs)
@@ -297,12 +365,13 @@ class SmoothCalibrator:
             assert isinstance(y, torch.Tensor), "eval_mod should return a tensor"
             return y
 
-        # the outputs to match: original weights (if given) on the original inputs (search.py:746-765)
+        # the outputs to match: original weights (if given) on the original inputs (search.py:746-765, 1011-1042)
         saved = []
-        if orig_x_wgts is not None:
-            saved = [(p, p.data) for p, _ in orig_x_wgts]
-            for p, w in orig_x_wgts:
-                p.data = w.to(device=p.data.device)
+        for originals in (orig_x_wgts, orig_y_wgts):
+            if originals is not None:
+                saved += [(p, p.data) for p, _ in originals]
+                for p, w in originals:
+                    p.data = w.to(device=p.data.device)
         ref_inputs = orig_eval_inputs or eval_inputs
         num_batches = len(ref_inputs.front().data)
         orig_opts = [forward(ref_inputs, i) for i in range(num_batches)]
@@ -310,7 +379,10 @@ class SmoothCalibrator:
             p.data = w
         while not self.is_done():
             self.ask()
-            self._process_wgts_centric_mod(wgts=x_wgts, mods=x_mods)
+            if outputs_centric:
+                self._process_opts_centric_mod(x_wgts=x_wgts, y_wgts=y_wgts, x_mods=x_mods, y_mods=y_mods)
+            else:
+                self._process_wgts_centric_mod(wgts=x_wgts, mods=x_mods)
             total = None
             for i in range(len(eval_inputs.front().data)):
                 y = (forward(eval_inputs, i) - orig_opts[i].to(x_wgts[0].device)).to(self.develop_dtype)
@@ -332,7 +404,8 @@ class SmoothLinearCalibrator(SmoothCalibrator):
 
 
 class SmoothAttentionCalibrator(SmoothCalibrator):
-    """Query / key smoothing (smooth.py:757-849): constructible for configuration parity; the search raises."""
+    """Query / key smoothing search (smooth.py:757-849): the scale multiplies the query projection's rows and
+    divides the key projection's, scored on the outputs of the attention module."""
 
     def __init__(self, config: SmoothCalibConfig, query_quantizer: Quantizer | None, key_quantizer: Quantizer | None,
                  num_heads: int = 1, num_head_repeats: int = 1, with_rope: bool = True,
@@ -340,6 +413,14 @@ class SmoothAttentionCalibrator(SmoothCalibrator):
         super().__init__(tensor_type=TensorType.Outputs, config=config, w_quantizer=None, x_quantizer=query_quantizer,
                          y_quantizer=key_quantizer, num_heads=num_heads, num_head_repeats=num_head_repeats,
                          with_rope=with_rope, develop_dtype=develop_dtype)
+
+    def calibrate(self, q_proj_weight: nn.Parameter, k_proj_weight: nn.Parameter, queries: TensorsCache,
+                  keys: TensorsCache, query_module: nn.Module, key_module: nn.Module,
+                  eval_module: nn.Module | None = None, eval_inputs: TensorsCache | None = None,
+                  eval_kwargs: dict[str, tp.Any] | None = None) -> torch.Tensor:
+        return super().calibrate(x_wgts=[q_proj_weight], y_wgts=[k_proj_weight], x_acts=queries, y_acts=keys,
+                                 x_mods=[query_module], y_mods=[key_module], eval_module=eval_module,
+                                 eval_inputs=eval_inputs, eval_kwargs=eval_kwargs)
 
 
 def _check_finite(param: nn.Parameter) -> None:
@@ -419,12 +500,27 @@ def smooth_linear_modules(prevs: nn.Module | tp.Sequence[nn.Module] | None, modu
 
 
 @torch.inference_mode()
-def smooth_attention(*, q_proj: nn.Linear, k_proj: nn.Linear, scale: torch.Tensor | None, num_heads: int = 1,
-                     num_head_repeats: int = 1, **kwargs) -> torch.Tensor:
-    """Apply a given query / key smoothing scale: q_proj rows are multiplied, k_proj rows divided
-    (smooth.py:1018-1109).  Searching for the scale is not implemented."""
+def smooth_attention(*, q_proj: nn.Linear, k_proj: nn.Linear, scale: torch.Tensor | None,
+                     config: SmoothCalibConfig | None = None, query_quantizer: Quantizer | None = None,
+                     key_quantizer: Quantizer | None = None, queries: TensorsCache | None = None,
+                     keys: TensorsCache | None = None, attn_q: nn.Module | None = None,
+                     attn_k: nn.Module | None = None, eval_inputs: TensorsCache | None = None,
+                     eval_module: nn.Module = None, eval_kwargs: dict[str, tp.Any] = None, num_heads: int = 1,
+                     num_head_repeats: int = 1, with_rope: bool = True,
+                     develop_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Find (if ``scale`` is None) and apply the query / key smoothing scale: q_proj rows are multiplied, k_proj
+    rows divided.  Returns the scale on the CPU (smooth.py:1018-1109)."""
     if scale is None:
-        raise NotImplementedError("the query / key smoothing search is not implemented; pass `scale`")
+        assert queries is not None and keys is not None and eval_inputs is not None
+        assert attn_q is not None and attn_k is not None, "modules must be provided"
+        scale = SmoothAttentionCalibrator(
+            config=config, query_quantizer=query_quantizer, key_quantizer=key_quantizer, num_heads=num_heads,
+            num_head_repeats=num_head_repeats, with_rope=with_rope, develop_dtype=develop_dtype).calibrate(
+            q_proj_weight=q_proj.weight, k_proj_weight=k_proj.weight, queries=queries, keys=keys,
+            query_module=attn_q, key_module=attn_k, eval_inputs=eval_inputs, eval_module=eval_module,
+            eval_kwargs=eval_kwargs)
+        gc.collect()
+        torch.cuda.empty_cache()
     upscale = scale.to(device=q_proj.weight.device)
     smooth_upscale_param(q_proj.weight, upscale, channels_dim=0)
     downscale = convert_smooth_upscale_to_downscale(upscale, num_heads=num_heads, num_head_repeats=num_head_repeats)

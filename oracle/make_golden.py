@@ -719,12 +719,105 @@ def gen_range_products(ref) -> None:
     with open(os.path.join(OUT, "range_products.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
+class ToyScores(torch.nn.Module):
+    """Query-key scores of a small grouped-query attention: the evaluation module of the query / key smoothing
+    fixtures.  ``attn_q`` / ``attn_k`` are the (identity) modules whose outputs the calibrator quantizes."""
+
+    def __init__(self, channels: int, heads: int, kv_heads: int, head_dim: int):
+        super().__init__()
+        nn = torch.nn
+        self.heads, self.kv_heads, self.head_dim = heads, kv_heads, head_dim
+        self.q_proj = nn.Linear(channels, heads * head_dim, bias=False)
+        self.k_proj = nn.Linear(channels, kv_heads * head_dim, bias=False)
+        self.attn_q, self.attn_k = nn.Identity(), nn.Identity()
+
+    def forward(self, x):
+        b, t, _ = x.shape
+        q = self.attn_q(self.q_proj(x)).view(b, t, self.heads, self.head_dim).transpose(1, 2)
+        k = self.attn_k(self.k_proj(x)).view(b, t, self.kv_heads, self.head_dim).transpose(1, 2)
+        k = k.repeat_interleave(self.heads // self.kv_heads, dim=1)
+        return q @ k.transpose(-1, -2)
+
+
+@torch.no_grad()
+def gen_smooth_attn(ref) -> None:
+    """Query / key smoothing search (deepcompressor/calib/smooth.py:757-849, 1018-1109; calib/search.py:996-1078)."""
+    from deepcompressor.calib import smooth as rs
+    from deepcompressor.calib.config import SearchBasedCalibStrategy
+    from deepcompressor.calib.config.smooth import SmoothCalibConfig, SmoothSpanMode
+    from deepcompressor.data.cache import TensorCache, TensorsCache
+    from deepcompressor.data.dtype import QuantDataType
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+    from deepcompressor.data.zero import ZeroPointDomain
+    from deepcompressor.quantizer import Quantizer as RefQuantizer
+    from deepcompressor.quantizer.config.base import QuantizerConfig as RefQuantizerConfig
+
+    arrays, meta = {}, {}
+    g = torch.Generator().manual_seed(4242)
+    plan = [
+        ("gqa_rope_k4", dict(heads=4, kv_heads=2, with_rope=True, quant_q=False, alpha=0.5, beta=0, spans=("AbsMax", "AbsMax"))),
+        ("mha_norope_q8k4", dict(heads=4, kv_heads=4, with_rope=False, quant_q=True, alpha=0.5, beta=-2,
+                                 spans=("AbsMax", "RootMeanSquare"))),
+        ("gqa_manual", dict(heads=4, kv_heads=2, with_rope=True, quant_q=False, alpha=0.5, beta=0, spans=("AbsMax", "AbsMax"),
+                            manual=True)),
+    ]
+    for tag, c in plan:
+        channels, head_dim = 48, 16
+        mod = ToyScores(channels, c["heads"], c["kv_heads"], head_dim)
+        mod.q_proj.weight.data = torch.randn(mod.q_proj.weight.shape, generator=g) * 0.2
+        mod.k_proj.weight.data = torch.randn(mod.k_proj.weight.shape, generator=g) * 0.2 * torch.exp(
+            torch.randn(c["kv_heads"] * head_dim, 1, generator=g))
+        xs = [torch.randn(2, 10, channels, generator=g) for _ in range(3)]
+        queries = [mod.q_proj(x) for x in xs]
+        keys = [mod.k_proj(x) for x in xs]
+        cache = lambda data: TensorsCache(TensorCache([d.clone() for d in data], channels_dim=-1,  # noqa: E731
+                                                      reshape=LinearReshapeFn(), num_cached=3, num_total=3, num_samples=6))
+        kq = RefQuantizer(RefQuantizerConfig(dtype=QuantDataType.from_str("uint4"), zero_point=ZeroPointDomain.PostScale,
+                                             group_shapes=((1, head_dim),), scale_dtypes=(torch.float16,)),
+                          channels_dim=-1, key="k")
+        qq = RefQuantizer(RefQuantizerConfig(dtype=QuantDataType.from_str("sint8"), zero_point=None,
+                                             group_shapes=((1, -1),), scale_dtypes=(torch.float16,)),
+                          channels_dim=-1, key="q") if c["quant_q"] else None
+        cfg = SmoothCalibConfig(spans=[tuple(SmoothSpanMode[m] for m in c["spans"])], alpha=c["alpha"], beta=c["beta"],
+                                num_grids=8, degree=2,
+                                strategy=SearchBasedCalibStrategy.Manual if c.get("manual") else SearchBasedCalibStrategy.GridSearch)
+        errors, scales = [], []
+        orig_tell = rs.SmoothCalibrator._tell
+
+        def spy(self, error, _orig=orig_tell):
+            errors.append(float(error[0]))
+            scales.append(self.candidate.numpy().copy())
+            return _orig(self, error)
+
+        rs.SmoothCalibrator._tell = spy
+        try:
+            q0, k0 = mod.q_proj.weight.data.clone(), mod.k_proj.weight.data.clone()
+            best = rs.smooth_attention(q_proj=mod.q_proj, k_proj=mod.k_proj, scale=None, config=cfg, query_quantizer=qq,
+                                       key_quantizer=kq, queries=cache(queries), keys=cache(keys), attn_q=mod.attn_q,
+                                       attn_k=mod.attn_k, eval_inputs=cache(xs), eval_module=mod, eval_kwargs={},
+                                       num_heads=c["heads"], num_head_repeats=c["heads"] // c["kv_heads"],
+                                       with_rope=c["with_rope"])
+        finally:
+            rs.SmoothCalibrator._tell = orig_tell
+        arrays[f"{tag}|wq"], arrays[f"{tag}|wk"] = q0.numpy(), k0.numpy()
+        arrays[f"{tag}|wq_out"], arrays[f"{tag}|wk_out"] = mod.q_proj.weight.data.numpy().copy(), mod.k_proj.weight.data.numpy().copy()
+        for i, x in enumerate(xs):
+            arrays[f"{tag}|x{i}"] = x.numpy()
+        arrays[f"{tag}|best_scale"] = best.numpy().copy()
+        arrays[f"{tag}|errors"] = np.array(errors, dtype=np.float64)
+        arrays[f"{tag}|scales"] = np.stack(scales)
+        meta[tag] = dict(c, channels=channels, head_dim=head_dim, num_candidates=len(errors),
+                         best_index=int(np.argmin(errors)) if errors else -1)
+    np.savez_compressed(os.path.join(OUT, "smooth_attn.npz"), **arrays)
+    with open(os.path.join(OUT, "smooth_attn.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
 
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "lowrank"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "lowrank"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)

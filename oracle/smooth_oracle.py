@@ -95,3 +95,62 @@ def candidate_error(weights, xs, scale, w_spec, x_spec, degree: float = 2) -> fl
         y0 = np.concatenate([x.astype(F32) @ w.astype(F32).T for w in weights], axis=-1)
         total += float(np.sum(np.power((y - y0).astype(F32), degree), dtype=np.float64))
     return total
+
+
+def _repeat_heads(span: np.ndarray, unique_heads: int, repeats: int) -> np.ndarray:
+    return np.broadcast_to(span.reshape(unique_heads, 1, -1), (unique_heads, repeats, span.size // unique_heads)).reshape(-1)
+
+
+def _share(span: np.ndarray, outer: int, inner: int, use_max: bool) -> np.ndarray:
+    v = span.reshape(outer, inner, -1)
+    r = v.max(axis=1, keepdims=True) if use_max else v.mean(axis=1, keepdims=True, dtype=F32)
+    return np.broadcast_to(r, v.shape).reshape(-1).astype(F32)
+
+
+def attention_spans(queries, keys, *, num_heads: int, num_head_repeats: int, with_rope: bool, key_mode: str,
+                    query_mode: str) -> tuple[np.ndarray, np.ndarray]:
+    """(alpha base, beta base) of the query / key smoothing search (smooth.py:300-383): key spans (one per key/value
+    head, repeated over the query heads sharing it) and query spans (shared inside each group of query heads);
+    with rotary embedding the two halves of every head share one span."""
+    grouped = num_heads > 1 and num_head_repeats > 1
+    unique = num_heads // num_head_repeats if grouped else 0
+    mode = {"AbsMax": "abs_max", "RootMeanSquare": "root_mean_square"}
+    q_span = channel_metric([q.reshape(-1, q.shape[-1]) for q in queries], queries[0].shape[-1], mode[query_mode])
+    k_span = channel_metric([k.reshape(-1, k.shape[-1]) for k in keys], keys[0].shape[-1], mode[key_mode])
+    if unique:
+        q_span = _share(q_span, unique, num_head_repeats, "Max" in query_mode)
+        k_span = _repeat_heads(k_span, unique, num_head_repeats)
+    if with_rope:
+        q_span = _share(q_span, num_heads, 2, "Max" in query_mode)
+        k_span = _share(k_span, num_heads, 2, "Max" in key_mode)
+    return k_span.astype(F32), q_span.astype(F32)
+
+
+def attention_candidate_error(wq, wk, xs, scale, *, num_heads: int, num_head_repeats: int, head_dim: int, q_spec,
+                              k_spec, degree: float = 2) -> float:
+    """Outputs error of one query / key smoothing candidate on float32 score modules (smooth.py:627-653,
+    search.py:1048-1077): q_proj rows * s, k_proj rows / s (first query head of each group), both products
+    fake-quantized, error of the q k^T scores against the unscaled, unquantized ones."""
+    s = scale.astype(F32)
+    kv_heads = num_heads // num_head_repeats
+    wq_s = (wq.astype(F32) * s[:, None]).astype(F32)
+    wk_s = (wk.astype(F32) / downscale_for_producer(s, num_heads, num_head_repeats)[:, None]).astype(F32)
+
+    def scores(x, a, b, quantize):
+        bsz, t, _ = x.shape
+        q, k = (x @ a.T).astype(F32), (x @ b.T).astype(F32)
+        if quantize:
+            if q_spec is not None:
+                q = qo.fake_quantize(q.reshape(-1, q.shape[-1]), "f32", q_spec, default_dtype="f32")["dequant"].reshape(q.shape)
+            if k_spec is not None:
+                k = qo.fake_quantize(k.reshape(-1, k.shape[-1]), "f32", k_spec, default_dtype="f32")["dequant"].reshape(k.shape)
+        q = q.reshape(bsz, t, num_heads, head_dim).transpose(0, 2, 1, 3)
+        k = np.repeat(k.reshape(bsz, t, kv_heads, head_dim).transpose(0, 2, 1, 3), num_head_repeats, axis=1)
+        return (q @ k.transpose(0, 1, 3, 2)).astype(F32)
+
+    total = 0.0
+    for x in xs:
+        x = x.astype(F32)
+        d = (scores(x, wq_s, wk_s, True) - scores(x, wq.astype(F32), wk.astype(F32), False)).astype(F32)
+        total += float(np.sum(np.power(d, degree), dtype=np.float64))
+    return total
