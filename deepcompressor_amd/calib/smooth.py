@@ -10,8 +10,7 @@ granularity).  What runs where:
 * fake quantization of the scaled tensors             -> the ``Quantizer`` kernels
 * the evaluation module's forward                     -> torch on the GPU (the module belongs to the caller)
 
-Not implemented (raise): ProductsError / ChannelGroup scoring of smoothing candidates, the low-rank-aware
-candidate processing.
+Not implemented (raise): ProductsError / ChannelGroup scoring of smoothing candidates.
 """
 
 from __future__ import annotations
@@ -275,9 +274,30 @@ class SmoothCalibrator:
         wq = self.w_quantizer.quantize(ws, kernel=None, default_dtype=dtype, develop_dtype=self.develop_dtype).data
         return scale_channels(wq, self.candidate, channels_dim, divide=True, out_dtype=dtype)
 
-    def _process_wgts_centric_mod(self, wgts: list[nn.Parameter], mods: list[nn.Module]) -> None:
+    def _process_wgts_centric_mod(self, wgts: list[nn.Parameter], mods: list[nn.Module],
+                                  splits: list[int] | None = None) -> None:
         if self.needs_w_quant_for_wgts and self.config.allow_low_rank and self.w_quantizer.is_enabled_low_rank():
-            raise NotImplementedError("low-rank-aware smoothing candidates are not implemented")
+            # smooth.py:588-623: the smoothed weight W s is split into a low-rank branch and a quantized remainder,
+            # both fed with x / s (the branch sees it unquantized, the remainder after the input quantizer)
+            assert len(wgts) == len(mods)
+            for w in wgts:
+                self._state_dict.append((w, w.data))
+                w.data = scale_channels(w.data, self.candidate, 1, divide=False)
+            input_packager = self.x_quantizer.get_input_packager() if self.needs_x_quant else None
+            channels_dim = self.x_quantizer.channels_dim if self.x_quantizer is not None else -1
+            for mod in mods:
+                self._hooks.append(ActivationSmoother(self.candidate, channels_dim, develop_dtype=self.develop_dtype,
+                                                      input_packager=input_packager).as_hook().register(mod))
+            bounds = [0, *(splits or []), len(wgts)]
+            for begin, end in zip(bounds[:-1], bounds[1:]):
+                qtensors, branches = self.w_quantizer.quantize_with_low_rank(wgts[begin:end], kernel=None,
+                                                                             develop_dtype=self.develop_dtype)
+                for qt, branch, w, mod in zip(qtensors, branches, wgts[begin:end], mods[begin:end], strict=True):
+                    w.data = qt.data
+                    self._hooks.append(branch.as_hook(input_packager=input_packager).register(mod))
+                    if self.needs_x_quant_for_wgts:
+                        self._hooks.append(self.x_quantizer.as_hook().register(mod))
+            return
         if self.needs_w_quant_for_wgts:
             for w in wgts:
                 self._state_dict.append((w, w.data))
@@ -382,7 +402,7 @@ class SmoothCalibrator:
             if outputs_centric:
                 self._process_opts_centric_mod(x_wgts=x_wgts, y_wgts=y_wgts, x_mods=x_mods, y_mods=y_mods)
             else:
-                self._process_wgts_centric_mod(wgts=x_wgts, mods=x_mods)
+                self._process_wgts_centric_mod(wgts=x_wgts, mods=x_mods, splits=kwargs.get("splits"))
             total = None
             for i in range(len(eval_inputs.front().data)):
                 y = (forward(eval_inputs, i) - orig_opts[i].to(x_wgts[0].device)).to(self.develop_dtype)

@@ -812,12 +812,75 @@ def gen_smooth_attn(ref) -> None:
     with open(os.path.join(OUT, "smooth_attn.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
+@torch.no_grad()
+def gen_smooth_lowrank(ref) -> None:
+    """Smoothing search whose candidates are scored with the low-rank branch in place (allow_low_rank,
+    deepcompressor/calib/smooth.py:580-625), as the SVDQuant configs run it."""
+    import torch.nn as nn
+    from deepcompressor.calib import smooth as rs
+    from deepcompressor.calib.config import SearchBasedCalibStrategy
+    from deepcompressor.calib.config.smooth import SmoothCalibConfig, SmoothSpanMode
+    from deepcompressor.data.cache import TensorCache, TensorsCache
+    from deepcompressor.data.dtype import QuantDataType
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+    from deepcompressor.quantizer import Quantizer as RefQuantizer
+    from deepcompressor.quantizer.config.base import QuantizerConfig as RefQuantizerConfig
+    from deepcompressor.quantizer.config.lowrank import QuantLowRankConfig
+
+    class Pair(nn.Module):
+        def __init__(self, a, b):
+            super().__init__()
+            self.a, self.b = a, b
+
+        def forward(self, x):
+            return torch.cat([self.a(x), self.b(x)], dim=-1)
+
+    arrays, meta = {}, {}
+    g = torch.Generator().manual_seed(777)
+    for tag, lr_kw, splits in (("shared", dict(rank=4), None), ("exclusive", dict(rank=4, exclusive=True), None),
+                               ("split", dict(rank=4), [1])):
+        a, b = nn.Linear(64, 40, bias=False), nn.Linear(64, 24, bias=False)
+        a.weight.data = torch.randn(40, 64, generator=g) * 0.08
+        b.weight.data = torch.randn(24, 64, generator=g) * 0.08
+        gains = torch.exp(torch.randn(64, generator=g) * 1.2)
+        xs = [torch.randn(2, 12, 64, generator=g) * gains for _ in range(3)]
+        arrays[f"{tag}|wa"], arrays[f"{tag}|wb"] = a.weight.data.numpy().copy(), b.weight.data.numpy().copy()
+        for i, x in enumerate(xs):
+            arrays[f"{tag}|x{i}"] = x.numpy().copy()
+        wq = RefQuantizer(RefQuantizerConfig(dtype=QuantDataType.from_str("sint4"), zero_point=None,
+                                             group_shapes=((1, 16),), scale_dtypes=(torch.float16,)), key="w",
+                          low_rank=QuantLowRankConfig(**lr_kw))
+        xq = RefQuantizer(RefQuantizerConfig(dtype=QuantDataType.from_str("sint8"), zero_point=None,
+                                             group_shapes=((1, -1),), scale_dtypes=(torch.float16,)), channels_dim=-1,
+                          key="x")
+        cfg = SmoothCalibConfig(spans=[(SmoothSpanMode.AbsMax, SmoothSpanMode.AbsMax)], alpha=0.5, beta=-2, num_grids=6,
+                                strategy=SearchBasedCalibStrategy.GridSearch, degree=2, allow_low_rank=True)
+        cache = TensorsCache(TensorCache(list(xs), channels_dim=-1, reshape=LinearReshapeFn(), num_cached=3, num_total=3,
+                                         num_samples=6, orig_device=torch.device("cpu")))
+        calib = rs.SmoothLinearCalibrator(cfg, wq, xq)
+        errors = []
+        orig_tell = calib._tell
+
+        def spy(error, _orig=orig_tell, _errors=errors):
+            _errors.append(float(error[0]))
+            return _orig(error)
+
+        calib._tell = spy
+        best = calib.calibrate(x_wgts=[a.weight, b.weight], x_acts=cache, x_mods=[a, b], eval_inputs=cache,
+                               eval_module=Pair(a, b), eval_kwargs={}, splits=splits)
+        arrays[f"{tag}|best_scale"] = best.numpy().copy()
+        arrays[f"{tag}|errors"] = np.array(errors, dtype=np.float64)
+        meta[tag] = dict(low_rank=lr_kw, splits=splits, num_candidates=len(errors), best_index=int(np.argmin(errors)))
+    np.savez_compressed(os.path.join(OUT, "smooth_lowrank.npz"), **arrays)
+    with open(os.path.join(OUT, "smooth_lowrank.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
 
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "lowrank"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)

@@ -154,3 +154,26 @@ def attention_candidate_error(wq, wk, xs, scale, *, num_heads: int, num_head_rep
         d = (scores(x, wq_s, wk_s, True) - scores(x, wq.astype(F32), wk.astype(F32), False)).astype(F32)
         total += float(np.sum(np.power(d, degree), dtype=np.float64))
     return total
+
+
+def candidate_error_low_rank(weights, xs, scale, w_spec, x_spec, rank: int, *, exclusive: bool = False,
+                             compensate: bool = False, splits=None, degree: float = 2) -> float:
+    """Outputs error of one smoothing candidate scored with the low-rank branch in place (smooth.py:588-623):
+    W s is split per group of modules into branch L and quantized remainder Q (quantize_with_low_rank); the module
+    computes Q(x / s) Q^T + (x / s) L^T -- the branch's hook sits before the input quantizer's."""
+    import lowrank_oracle as lo
+
+    s = scale.astype(F32)
+    scaled = [(w.astype(F32) * s[None, :]).astype(F32) for w in weights]
+    bounds = [0, *(splits or []), len(weights)]
+    parts = []
+    for begin, end in zip(bounds[:-1], bounds[1:]):
+        parts += lo.joint(scaled[begin:end], "f32", w_spec, rank, exclusive=exclusive, compensate=compensate)
+    total = 0.0
+    for x in xs:
+        xd = (x.astype(F32) / s).astype(F32)
+        xq = qo.fake_quantize(xd.reshape(-1, xd.shape[-1]), "f32", x_spec, default_dtype="f32")["dequant"].reshape(x.shape)
+        y = np.concatenate([(xq @ q.T + xd @ l.T).astype(F32) for q, l in parts], axis=-1)
+        y0 = np.concatenate([x.astype(F32) @ w.astype(F32).T for w in weights], axis=-1)
+        total += float(np.sum(np.power((y - y0).astype(F32), degree), dtype=np.float64))
+    return total
