@@ -71,31 +71,66 @@ def build_objects():
     return Quantizer, qcfg, rcfg, gcfg
 
 
-def quantize_layer(weights, caches, objs, syrk_events=None):
-    """The hot path for one layer; returns the dequantized weights (kept so nothing is optimised away)."""
+def quantize_layer(weights, caches, objs, syrk_events=None, streams: int = 1):
+    """The hot path for one layer; returns the dequantized weights (kept so nothing is optimised away).
+
+    ``streams`` > 1: the linears are grouped by the activations they share (q/k/v, o, gate/up, down); the groups
+    are independent and run concurrently, one HIP stream and host thread each."""
     import torch.nn as nn
 
     from deepcompressor_amd import _lib
     from deepcompressor_amd.calib import calibrate_dynamic_range
     from deepcompressor_amd.data.common import TensorType
+    from deepcompressor_amd.parallel import run_on_streams
     from deepcompressor_amd.quantizer.kernel import gptq as gptq_mod
 
     Quantizer, qcfg, rcfg, gcfg = objs
-    out = {}
-    for name, _, c, key in LLAMA3_8B_LAYER:
-        w = weights[name]
-        q = Quantizer(qcfg, key=name, kernel=gcfg, develop_dtype=torch.float32)
-        ranges = calibrate_dynamic_range(TensorType.Weights, rcfg, True, q, modules=[None], activations=None,
-                                         weights=[nn.Parameter(w, requires_grad=False)])
-        if syrk_events is not None and gptq_mod._hessian_cache["key"] != gptq_mod._inputs_key(caches[key], w.device):
+
+    def profiled_hessian(key, c):
+        if syrk_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             # torch creates the HIP event lazily on first record; record once so the handles exist
             e0.record(), e1.record()
             _lib.lib().dcq_profile_next_hessian(e0.cuda_event, e1.cuda_event)
             syrk_events.append((e0, e1, c))
-        out[name] = q.quantize(w, dynamic_range=ranges[0], inputs=caches[key]).data
-    gptq_mod.clear_hessian_cache()
-    return out
+        gptq_mod.prepare_hessians([caches[key]], weights["q_proj"].device)
+
+    def run_group(members):
+        out = {}
+        for name, _, c, key in members:
+            w = weights[name]
+            q = Quantizer(qcfg, key=name, kernel=gcfg, develop_dtype=torch.float32)
+            ranges = calibrate_dynamic_range(TensorType.Weights, rcfg, True, q, modules=[None], activations=None,
+                                             weights=[nn.Parameter(w, requires_grad=False)])
+            out[name] = q.quantize(w, dynamic_range=ranges[0], inputs=caches[key]).data
+        return out
+
+    groups: dict[str, list] = {}
+    for row in LLAMA3_8B_LAYER:
+        groups.setdefault(row[3], []).append(row)
+    try:
+        if streams <= 1:
+            out = {}
+            for key, members in groups.items():
+                profiled_hessian(key, members[0][2])
+                out.update(run_group(members))
+                gptq_mod.clear_hessian_cache()
+            return out
+        # phase 1: the Hessians, one after the other, each launch with the whole chip to itself; phase 2: the
+        # latency-bound rest (search, inverse factor, sweeps) of the independent groups side by side.
+        # longest pipeline first (cost ~ C^3 for the factor, R C^2 for the sweeps)
+        order = sorted(groups.values(), key=lambda ms: -(ms[0][2] ** 2) * (ms[0][2] + sum(m[1] for m in ms)))
+        for ms in order:
+            profiled_hessian(ms[0][3], ms[0][2])
+        buckets = [order[i::streams] for i in range(min(streams, len(order)))]
+        results = run_on_streams([lambda b=b: [run_group(ms) for ms in b] for b in buckets])
+        out = {}
+        for bucket in results:
+            for part in bucket:
+                out.update(part)
+        return out
+    finally:
+        gptq_mod.clear_hessian_cache()
 
 
 def stage_rates(device, weights, objs) -> dict:
@@ -170,6 +205,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=128 * 2048, help="calibration tokens (contract value: 262144)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="run the independent groups of linears of a layer concurrently on this many HIP streams")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,13 +225,13 @@ def main() -> None:
     objs = build_objects()
     weights, caches = make_layer(device, args.tokens, seed=1234 + rank)
     for _ in range(args.warmup):
-        quantize_layer(weights, caches, objs)
+        quantize_layer(weights, caches, objs, streams=args.streams)
     torch.cuda.synchronize()
     barrier_and_max(0.0, world, device)
     syrk_events: list = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        outputs = quantize_layer(weights, caches, objs, syrk_events)
+        outputs = quantize_layer(weights, caches, objs, syrk_events, streams=args.streams)
     torch.cuda.synchronize()
     elapsed = barrier_and_max(time.perf_counter() - t0, world, device)
     del outputs
@@ -224,7 +261,7 @@ def main() -> None:
                                    "linears of one Llama-3-8B decoder layer per step, bf16 weights/activations, "
                                    f"{args.tokens} calibration tokens resident in HBM",
                        "params_per_step": PARAMS_PER_LAYER, "tokens": args.tokens,
-                       "parallelism": f"independent layers x{world}"},
+                       "parallelism": f"independent layers x{world}", "streams_per_gpu": args.streams},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": achieved / 2500.0, "traffic": traffic, "kernel": "syrk_kernel (H += 2/n X^T X, bf16 MFMA)",
                          "launches": len(syrk_events), "avg_launch_ms": syrk_ms / max(1, len(syrk_events)),

@@ -9,7 +9,8 @@ from __future__ import annotations
 
 import torch
 
-__all__ = ["assign_round_robin", "assign_by_cost", "barrier_and_max", "all_reduce_sum", "row_shard", "map_rows_sharded"]
+__all__ = ["assign_round_robin", "assign_by_cost", "barrier_and_max", "all_reduce_sum", "row_shard", "map_rows_sharded",
+           "run_on_streams"]
 
 
 def assign_round_robin(num_items: int, world: int, rank: int) -> list[int]:
@@ -84,3 +85,66 @@ def _all_gather_ragged(parts: list[torch.Tensor], mine: torch.Tensor, rank: int,
         if r == rank:
             parts[r].copy_(mine)
         dist.broadcast(parts[r], src=r)
+
+
+def run_on_streams(jobs, device: torch.device | str | None = None, priorities: list[int] | None = None) -> list:
+    """Run independent jobs concurrently on ONE GPU, each on its own HIP stream driven by its own host thread, and
+    return their results in order.
+
+    The calibration pipeline of a linear alternates kernels that fill the chip (the Hessian SYRK, big GEMMs) with
+    kernels that cannot (the 128-column sweep, the single-workgroup panel factorisation, small GEMMs) and with
+    host-side checks that wait for the device (a failed factorisation must be seen to raise the damping).  Groups of
+    linears that do not share activations are independent, so their pipelines may interleave: while one group's
+    latency-bound kernels run, another group's matrix-core kernels use the idle CUs.  One thread per stream keeps
+    each pipeline's host waits from stalling the others; per-thread state of the kernels (workspaces, memoised
+    Hessians) keeps them apart.
+
+    Every stream first waits for the work already queued on the caller's current stream (the inputs), and the
+    caller's stream waits for every job's stream before this returns, so results can be used as usual afterwards.
+    ``priorities``: optional HIP stream priority per job (lower number = higher priority)."""
+    import threading
+
+    jobs = list(jobs)
+    if len(jobs) <= 1:
+        return [job() for job in jobs]
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    caller = torch.cuda.current_stream(dev)
+    streams = [torch.cuda.Stream(device=dev, priority=(priorities[i] if priorities else 0)) for i in range(len(jobs))]
+    results, errors = [None] * len(jobs), [None] * len(jobs)
+    grad_mode, inference = torch.is_grad_enabled(), torch.is_inference_mode_enabled()
+
+    def work(i: int) -> None:
+        try:
+            torch.cuda.set_device(dev)
+            streams[i].wait_stream(caller)
+            with torch.inference_mode(inference), torch.set_grad_enabled(grad_mode), torch.cuda.stream(streams[i]):
+                results[i] = jobs[i]()
+        except BaseException as exc:  # noqa: BLE001 -- re-raised in the caller's thread
+            errors[i] = exc
+
+    threads = [threading.Thread(target=work, args=(i,), name=f"dcq-stream-{i}") for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for s in streams:
+        caller.wait_stream(s)
+    for exc in errors:
+        if exc is not None:
+            raise exc
+    _record_stream(results, caller)
+    return results
+
+
+def _record_stream(obj, stream) -> None:
+    """Tell the allocator that tensors made on a job's stream are now used on ``stream`` (so their memory is not
+    handed out again on the job's stream while ``stream`` still reads it)."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)

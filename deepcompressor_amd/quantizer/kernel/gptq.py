@@ -10,6 +10,7 @@ lazy update between blocks is that same GEMM (``dcq_gemm_f32``).
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass
 
 import torch
@@ -25,7 +26,7 @@ from ...utils.config import configclass
 from ..config.kernel import BaseQuantKernel, BaseQuantKernelConfig
 
 __all__ = ["QuantGptqConfig", "QuantGptqKernel", "gptq_quantize", "hessian_accumulate", "hessian_of",
-           "clear_hessian_cache", "cholesky_inverse_upper", "gemm_f32"]
+           "prepare_hessians", "clear_hessian_cache", "cholesky_inverse_upper", "gemm_f32"]
 
 LAZY_BLOCKS = 4  # sweep blocks per far-column update
 SWEEP_COLUMNS = 128  # columns per sweep launch; the result does not depend on the block width (only fp order does)
@@ -65,20 +66,58 @@ class QuantGptqKernel(BaseQuantKernel):
                              range_bound=range_bound)
 
 
-_workspaces: dict[torch.device, torch.Tensor] = {}
-# The weights fed by the same activations (q/k/v, gate/up) share one Hessian: the most recent one is kept,
-# keyed by the identity of the cached activation tensors.
-_hessian_cache: dict = {"key": None, "value": None}
+class _State(threading.local):
+    """Per host thread, because independent groups of linears may be driven from one thread per HIP stream
+    (``deepcompressor_amd.parallel.run_on_streams``): a workspace or memo shared across streams would race.
+
+    workspaces: one scratch buffer per device.
+    hessian: the weights fed by the same activations (q/k/v, gate/up) share one Hessian -- the most recent one is
+    kept, keyed by the identity of the cached activation tensors.
+    factor: ... and therefore one act-order permutation and one inverse factor, kept for the most recent Hessian
+    tensor (held by reference, so its storage cannot be recycled under the key)."""
+
+    def __init__(self):
+        self.workspaces: dict[torch.device, torch.Tensor] = {}
+        self.hessian: dict = {"key": None, "value": None}
+        self.factor: dict = {"key": None, "value": None}
 
 
-# ... and therefore one act-order permutation and one inverse factor: kept for the most recent Hessian tensor
-# (held by reference, so its storage cannot be recycled under the key).
-_factor_cache: dict = {"key": None, "value": None}
+_state = _State()
+# Hessians computed ahead of time by ``prepare_hessians`` (any number, visible to every host thread) until
+# ``clear_hessian_cache``; read-only once stored.
+_prepared: dict = {}
+_prepared_lock = threading.Lock()
 
 
 def clear_hessian_cache() -> None:
-    _hessian_cache["key"] = _hessian_cache["value"] = None
-    _factor_cache["key"] = _factor_cache["value"] = None
+    """Drop this thread's memoised Hessian and inverse factor, and every prepared Hessian."""
+    _state.hessian["key"] = _state.hessian["value"] = None
+    _state.factor["key"] = _state.factor["value"] = None
+    with _prepared_lock:
+        _prepared.clear()
+
+
+def prepare_hessians(caches, device: torch.device) -> list[torch.Tensor]:
+    """Compute the Hessian of every activation cache in ``caches`` now, one after the other on the current stream
+    (each launch has the whole chip), and keep them for ``hessian_of`` calls from any thread until
+    ``clear_hessian_cache``.  The pipelines that consume them (inverse factor, sweeps) are latency-bound and may then
+    run concurrently on several streams without slowing the matrix-core SYRKs down."""
+    out = []
+    for inputs in caches:
+        key = _inputs_key(inputs, device)
+        with _prepared_lock:
+            hit = _prepared.get(key)
+        if hit is None:
+            hit = _compute_hessian(inputs, device)
+            with _prepared_lock:
+                _prepared[key] = hit
+        out.append(hit)
+    return out
+
+
+def cached_hessian_key():
+    """Key of this thread's memoised Hessian (see ``_inputs_key``), or None."""
+    return _state.hessian["key"]
 
 
 def _inputs_key(inputs: TensorCache, device: torch.device):
@@ -89,20 +128,30 @@ def _inputs_key(inputs: TensorCache, device: torch.device):
 def hessian_of(inputs: TensorCache, device: torch.device) -> torch.Tensor:
     """2 / num_samples * sum_x x^T x over the cache (float32, C x C), memoised for the last cache seen."""
     key = _inputs_key(inputs, device)
+    with _prepared_lock:
+        hit = _prepared.get(key)
+    if hit is not None:
+        return hit
+    _hessian_cache = _state.hessian
     if _hessian_cache["key"] != key:
         _hessian_cache["key"] = _hessian_cache["value"] = None
-        hessian = None
-        alpha = 2.0 / inputs.num_samples
-        for x in inputs.data:
-            x2 = inputs.reshape(x.view(-1, *x.shape[inputs.channels_dim:]))
-            if hessian is None:
-                hessian = torch.zeros((x2.shape[1], x2.shape[1]), device=device, dtype=torch.float32)
-            hessian_accumulate(hessian, x2.to(device=device, non_blocking=True), alpha)
-        _hessian_cache["key"], _hessian_cache["value"] = key, hessian
+        _hessian_cache["key"], _hessian_cache["value"] = key, _compute_hessian(inputs, device)
     return _hessian_cache["value"]
 
 
+def _compute_hessian(inputs: TensorCache, device: torch.device) -> torch.Tensor:
+    hessian = None
+    alpha = 2.0 / inputs.num_samples
+    for x in inputs.data:
+        x2 = inputs.reshape(x.view(-1, *x.shape[inputs.channels_dim:]))
+        if hessian is None:
+            hessian = torch.zeros((x2.shape[1], x2.shape[1]), device=device, dtype=torch.float32)
+        hessian_accumulate(hessian, x2.to(device=device, non_blocking=True), alpha)
+    return hessian
+
+
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    _workspaces = _state.workspaces
     ws = _workspaces.get(device)
     if ws is None or ws.numel() < nbytes:
         _workspaces.pop(device, None)
@@ -113,7 +162,7 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
 
 
 def release_workspaces() -> None:
-    _workspaces.clear()
+    _state.workspaces.clear()
 
 
 def hessian_accumulate(hessian: torch.Tensor, x: torch.Tensor, alpha: float) -> None:
@@ -186,6 +235,7 @@ def _inverse_factor_of(hessian: torch.Tensor, config: QuantGptqConfig):
     """(dead channels, act-order permutation, its inverse, U) of a Hessian (gptq.py:199-233), memoised for the most
     recent Hessian tensor: weights that share their inputs share all four."""
     key = (hessian._version, config.damp_percentage, config.num_inv_tries)
+    _factor_cache = _state.factor
     hit = _factor_cache["key"]
     if hit is not None and hit[0] is hessian and hit[1] == key:
         return _factor_cache["value"]

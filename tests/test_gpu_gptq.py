@@ -213,3 +213,44 @@ def test_gptq_row_shards_equal_unsharded():
         slabs.append(q.quantize(w[b:e].contiguous(), kernel=kern, inputs=cache, return_with_dequant=False,
                                 return_with_quant=True).qdata)
     assert torch.equal(torch.cat(slabs, dim=0), full)
+
+
+def test_groups_on_streams_equal_serial():
+    """Independent linears run side by side (one HIP stream and host thread each, Hessians prepared beforehand)
+    give bit-identical codes to running them one after the other."""
+    from deepcompressor_amd.parallel import run_on_streams
+    from deepcompressor_amd.quantizer.kernel import gptq as gptq_mod
+
+    case = FQ.meta["cases"]["uint4_post_g128_f16s"]
+    g = torch.Generator().manual_seed(5)
+    shapes = [(256, 512), (384, 768), (128, 1024), (512, 256)]
+    ws = [(torch.randn(r, c, generator=g) * 0.02).to(torch.bfloat16).cuda() for r, c in shapes]
+    xs = [(torch.randn(2048, c, generator=g) * torch.exp(0.5 * torch.randn(c, generator=g))).to(torch.bfloat16).cuda()
+          for _, c in shapes]
+    caches = [TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_samples=2048, orig_device=x.device)
+              for x in xs]
+    kern = QuantGptqConfig()
+
+    def job(i):
+        q = build_quantizer(case)
+        return q.quantize(ws[i], kernel=kern, inputs=caches[i], return_with_dequant=False, return_with_quant=True).qdata
+
+    serial = [job(i) for i in range(len(ws))]
+    gptq_mod.clear_hessian_cache()
+    for _ in range(2):
+        hs = gptq_mod.prepare_hessians(caches, ws[0].device)
+        assert len(hs) == len(ws) and gptq_mod.hessian_of(caches[2], ws[0].device) is hs[2]
+        side = run_on_streams([lambda i=i: job(i) for i in range(len(ws))])
+        gptq_mod.clear_hessian_cache()
+        for a, b in zip(serial, side):
+            assert torch.equal(a, b)
+
+
+def test_run_on_streams_propagates_errors():
+    from deepcompressor_amd.parallel import run_on_streams
+
+    def bad():
+        raise ValueError("boom")
+
+    with pytest.raises(ValueError, match="boom"):
+        run_on_streams([lambda: torch.ones(4, device="cuda"), bad])
