@@ -660,4 +660,36 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
   return DCQ_OK;
 }
 
+int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64_t C, const float* U,
+                   const float* scale, const float* zero, float zero_scalar, int32_t row_group_size,
+                   int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
+                   int32_t lazy_blocks, dcq_stream_t stream) {
+  DCQ_REQUIRE(lazy_blocks >= 1 && lazy_blocks <= 64, DCQ_ERR_ARGUMENT, "lazy_blocks must be in [1, 64]");
+  DCQ_REQUIRE(C > 0 && C < (1ll << 31), DCQ_ERR_ARGUMENT, "bad C");
+  if (R == 0) return DCQ_OK;
+  const int64_t group_cols = static_cast<int64_t>(kSweepCols) * lazy_blocks;
+  for (int64_t g0 = 0; g0 < C; g0 += group_cols) {
+    const int64_t g_end = g0 + group_cols < C ? g0 + group_cols : C;
+    for (int64_t c0 = g0; c0 < g_end; c0 += kSweepCols) {
+      const int32_t bc = static_cast<int32_t>(C - c0 < kSweepCols ? C - c0 : kSweepCols);
+      float* err_block = Err + (c0 - g0);
+      int rc = dcq_gptq_sweep_block(step, W, ldw, R, C, U, static_cast<int32_t>(c0), bc, scale, zero, zero_scalar,
+                                    row_group_size, col_group_size, col_groups, perm, Q, err_block, group_cols, stream);
+      if (rc != DCQ_OK) return rc;
+      const int64_t c_end = c0 + bc;
+      if (c_end < g_end) {  // the rest of this group, right away (K = 128: a block short of 128 is the last one)
+        rc = dcq_gemm_f32(err_block, group_cols, 0, U + c0 * C + c_end, C, W + c_end, ldw, R, g_end - c_end, kSweepCols,
+                          -1.0f, 1.0f, stream);
+        if (rc != DCQ_OK) return rc;
+      }
+    }
+    if (g_end < C) {  // everything right of the group, once (a full group: its blocks are all 128 wide)
+      const int rc = dcq_gemm_f32(Err, group_cols, 0, U + g0 * C + g_end, C, W + g_end, ldw, R, C - g_end, group_cols,
+                                  -1.0f, 1.0f, stream);
+      if (rc != DCQ_OK) return rc;
+    }
+  }
+  return DCQ_OK;
+}
+
 }  // extern "C"

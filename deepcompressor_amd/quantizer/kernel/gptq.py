@@ -2,7 +2,7 @@
 
 Same config fields and kernel interface as the reference.  The Hessian X^T X runs on the matrix cores
 (``dcq_hessian_accumulate``), the column sweep of each 128-column block is one HIP kernel with rows as the
-parallel axis (``dcq_gptq_sweep_block``), the inverse Cholesky factor of the damped Hessian is a blocked
+parallel axis (``dcq_gptq_sweep``), the inverse Cholesky factor of the damped Hessian is a blocked
 factorisation + triangular inverse on the float32 matrix-core GEMM (``dcq_cholesky_inverse_upper``), and the
 lazy update between blocks is that same GEMM (``dcq_gemm_f32``).
 """
@@ -295,21 +295,8 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     # writes the far part of W LAZY_BLOCKS times less often.
     group_cols = SWEEP_COLUMNS * LAZY_BLOCKS
     err = torch.empty((R, group_cols), device=dev, dtype=torch.float32)
-    stream = stream_of(dev)
-    raw = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    for g0 in range(0, Cn, group_cols):
-        g_end = min(g0 + group_cols, Cn)
-        for c0 in range(g0, g_end, SWEEP_COLUMNS):
-            bc = min(SWEEP_COLUMNS, Cn - c0)
-            err_block = err[:, c0 - g0:c0 - g0 + SWEEP_COLUMNS]
-            check(lib().dcq_gptq_sweep_block(C.byref(step), ptr(W), Cn, R, Cn, ptr(U), c0, bc, ptr(s2), ptr(z2),
-                                             z_scalar, rg_size, cg_size, n_cg, ptr(perm), ptr(Q), raw(err_block),
-                                             group_cols, stream), "dcq_gptq_sweep_block")
-            c_end = c0 + bc
-            if c_end < g_end:  # the rest of this group, right away
-                gemm_f32(err_block, U[c0:c_end, c_end:g_end], W[:, c_end:g_end], alpha=-1.0, beta=1.0)
-        if g_end < Cn:  # everything right of the group, once (a full group: its blocks are all 128 wide)
-            gemm_f32(err, U[g0:g_end, g_end:], W[:, g_end:], alpha=-1.0, beta=1.0)
+    check(lib().dcq_gptq_sweep(C.byref(step), ptr(W), Cn, R, Cn, ptr(U), ptr(s2), ptr(z2), z_scalar, rg_size, cg_size,
+                               n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, stream_of(dev)), "dcq_gptq_sweep")
     Q = Q[:, inverse_perm]
     assert not Q.isnan().any(), "GPTQ Quantized tensor contains NaN."
     assert not Q.isinf().any(), "GPTQ Quantized tensor contains Inf."

@@ -231,6 +231,13 @@ int dcq_selftest_division(const float* x, const float* s, float* fast, float* re
  * for the caller's lazy update W[:, c0+bc:] -= Err @ U[c0:c0+bc, c0+bc:] (gptq.py:269); ld_err > 128 lets the
  * caller collect the errors of several blocks side by side and update far columns with one larger product.
  * scale/zero: [R / row_group_size][col_groups].
+ *
+ * dcq_gptq_sweep: the whole column loop (gptq.py:234-269) in one call -- every block through
+ * dcq_gptq_sweep_block and the lazy updates through dcq_gemm_f32, all enqueued on `stream` without returning
+ * to the host.  The updates are regrouped: the errors of `lazy_blocks` consecutive blocks are kept side by
+ * side in Err[R][128 * lazy_blocks]; columns inside such a group are updated after every block, the columns
+ * right of it once per group with one product of depth 128 * lazy_blocks (the same sums as the reference's
+ * per-block update; only the float32 summation order differs).  U is [C][C] with leading dimension C.
  * ------------------------------------------------------------------------------------------- */
 int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C);
 
@@ -246,6 +253,11 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
                          int32_t bc, const float* scale, const float* zero, float zero_scalar, int32_t row_group_size,
                          int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
                          int64_t ld_err, dcq_stream_t stream);
+
+int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64_t C, const float* U,
+                   const float* scale, const float* zero, float zero_scalar, int32_t row_group_size,
+                   int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
+                   int32_t lazy_blocks, dcq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense float32 linear algebra of GPTQ on the matrix cores.
