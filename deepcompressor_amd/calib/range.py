@@ -62,7 +62,9 @@ class DynamicRangeCalibrator:
 
     # ---- shapes (calib/range.py:113-139) ---------------------------------------------------------------------
     def _set_shapes(self, shape: torch.Size) -> None:
-        view = infer_view_shape(shape, self.quantizer.config.largest_group_shape)
+        self._set_shapes_from_view(infer_view_shape(shape, self.quantizer.config.largest_group_shape), shape)
+
+    def _set_shapes_from_view(self, view: torch.Size, shape: torch.Size | None = None) -> None:
         self.view_shape = view
         self.pos_view_shape = torch.Size([1, 1, view[2], *([1] * (len(view) - 3))])
         self.range_shape = torch.Size([gs if i % 2 == 0 else 1 for i, gs in enumerate(view)])
@@ -108,15 +110,25 @@ class DynamicRangeCalibrator:
                 self.granularity = SearchBasedCalibGranularity.Layer
 
     @torch.inference_mode()
-    def calibrate(self, x_wgts: list[nn.Parameter] | None = None, *, x_acts: TensorsCache | None = None,
-                  x_mods: list[nn.Module] | None = None, eval_inputs: TensorsCache | None = None,
+    def calibrate(self, x_wgts: list[nn.Parameter] | None = None, *, y_wgts: list[nn.Parameter] | None = None,
+                  x_acts: TensorsCache | None = None, y_acts: TensorsCache | None = None,
+                  x_mods: list[nn.Module] | None = None, y_mods: list[nn.Module] | None = None,
+                  eval_inputs: TensorsCache | None = None,
                   eval_module: nn.Module | None = None, eval_kwargs: dict[str, tp.Any] | None = None,
                   orig_x_wgts: list[tuple[nn.Parameter, torch.Tensor]] | None = None,
-                  orig_x_acts: TensorsCache | None = None, orig_eval_inputs: TensorsCache | None = None,
+                  orig_y_wgts: list[tuple[nn.Parameter, torch.Tensor]] | None = None,
+                  orig_x_acts: TensorsCache | None = None, orig_y_acts: TensorsCache | None = None,
+                  orig_eval_inputs: TensorsCache | None = None,
                   record_errors: bool = False, **unused) -> DynamicRange:
-        """Run the whole grid search (SearchBasedCalibrator.calibrate, calib/search.py:532-684, weights only)."""
+        """Run the whole grid search (SearchBasedCalibrator.calibrate, calib/search.py:532-684)."""
         if self.tensor_type != TensorType.Weights:
-            raise self._unsupported(f"tensor type {self.tensor_type.name}")
+            inputs = self.tensor_type == TensorType.Inputs
+            self.path = "general"
+            self._calibrate_acts(acts=x_acts if inputs else y_acts, mods=x_mods if inputs else y_mods,
+                                 eval_inputs=eval_inputs, eval_module=eval_module, eval_kwargs=eval_kwargs or {},
+                                 orig_wgts=(orig_x_wgts or []) + (orig_y_wgts or []),
+                                 orig_eval_inputs=orig_eval_inputs, record_errors=record_errors)
+            return self.get_best()
         if not self.is_clamp_based():
             raise self._unsupported("allow_scale on a non-static tensor")
         assert x_wgts is not None and len(x_wgts) == 1, "The weight should be a single tensor."
@@ -329,16 +341,20 @@ class DynamicRangeCalibrator:
         """calib/range.py:183-221.  Per channel group the reference's own update cannot run (it reshapes the mask
         expanded over rows to the per-channel-group ratio shape, calib/range.py:208-215, which raises); the mask is
         applied to the ratio before it is expanded here."""
+        clamp_based = candidate.max is not None
         if self.best_error is None:
             self.best_error = error.clone()
-            self.best_range.min = None if candidate.min is None else candidate.min.expand(self.range_shape).clone()
-            self.best_range.max = candidate.max.expand(self.range_shape).clone()
+            if clamp_based:
+                self.best_range.min = None if candidate.min is None else candidate.min.expand(self.range_shape).clone()
+                self.best_range.max = candidate.max.expand(self.range_shape).clone()
             self.best_range.ratio = torch.full(size=self.ratio_shape, fill_value=ratio, device=device,
                                                dtype=self.develop_dtype)
             return
         pos = error < self.best_error  # strict: the earlier (larger) ratio wins ties
         self.best_error[pos] = error[pos]
         self.best_range.ratio[pos.view(self.ratio_shape)] = ratio
+        if not clamp_based:
+            return
         if self.granularity == SearchBasedCalibGranularity.Group:
             rpos = pos.view(self.range_shape)
         elif self.granularity == SearchBasedCalibGranularity.ChannelGroup:
@@ -350,9 +366,157 @@ class DynamicRangeCalibrator:
             self.best_range.min[rpos] = candidate.min.expand(self.range_shape)[rpos]
 
     def get_best(self) -> DynamicRange:
+        """calib/range.py:152-164."""
         if self.static:
             return DynamicRange(min=self.best_range.min, max=self.best_range.max)
-        return DynamicRange(min=self.best_range.min, max=self.best_range.max, ratio=1.0)
+        if self.is_clamp_based():
+            return DynamicRange(min=self.best_range.min, max=self.best_range.max, ratio=1.0)
+        return DynamicRange(ratio=self.best_range.ratio.view(self.ratio_view_shape))
+
+    # ---- activations (calib/range.py:101-150, calib/search.py:839-1078) --------------------------------------
+    def _calibrate_acts(self, acts, mods, eval_inputs, eval_module, eval_kwargs, orig_wgts, orig_eval_inputs,
+                        record_errors: bool) -> None:
+        """Range of a module's inputs or outputs.  The cached batches, flattened ahead of the channel dimension, are
+        viewed with the whole first dimension inside the group (``skip_first_dim``), so a static range is shared by
+        all tokens.  Clamp-based search (static tensors, or ``allow_scale`` off): candidates are the measured range
+        times each ratio; otherwise the candidate is the ratio itself, applied to the range the quantizer measures
+        on the fly.  A candidate is scored on the tensor (inputs only: |Q(x) - x|^degree per channel group or in
+        total, summed per batch in the tensor's dtype and added up in that dtype as the reference does) or on the
+        evaluation module's outputs with the quantizer hooked onto the modules."""
+        what = "input" if self.tensor_type == TensorType.Inputs else "output"
+        assert acts is not None, f"The {what} activations should be provided."
+        assert acts.num_tensors == 1, f"Only one {what} is allowed, got {acts.num_tensors}"
+        cache = acts.front()
+        q, zd = self.quantizer, q_zero_domain(self.quantizer)
+        is_fp = q.config.quant_dtype.is_float_point
+        # objective / granularity as the reference resolves them (calib/search.py:361-414)
+        self.objective, self.granularity = self.config.objective, self.config.granularity
+        if self.tensor_type == TensorType.Outputs:
+            self.objective, self.granularity = SearchBasedCalibObjective.OutputsError, SearchBasedCalibGranularity.Layer
+        elif self.objective == SearchBasedCalibObjective.OutputsError:
+            assert eval_inputs is not None, "eval_inputs should not be None when objective is OutputsError"
+            assert eval_module is not None, "eval_module should not be None when OutputsError"
+            if (isinstance(eval_module, (nn.Linear, nn.Conv2d))
+                    and self.granularity.value < SearchBasedCalibGranularity.Layer.value):
+                self.objective = SearchBasedCalibObjective.ProductsError
+            else:
+                self.granularity = SearchBasedCalibGranularity.Layer
+        if self.objective == SearchBasedCalibObjective.ProductsError:
+            raise self._unsupported("ProductsError for activations")
+        if self.pre_scale is not None:
+            raise self._unsupported("progressive quantizers on activations")
+        device = _device_of(cache, mods, eval_module)
+        batches = [t.to(device) for t in cache.get_standardized_data(reshape=False)]
+        assert all(t.shape == batches[0].shape for t in batches), "all batches must have the same shape"
+        view = infer_view_shape(batches[0].shape, q.config.largest_group_shape, skip_first_dim=True)
+        self._set_shapes_from_view(view)
+        if self.is_clamp_based():
+            self.base_range = DynamicRange.construct([t.view(view) for t in batches], zero_domain=zd,
+                                                     is_float_point=is_fp)
+        if self.objective == SearchBasedCalibObjective.TensorError:
+            if self.granularity == SearchBasedCalibGranularity.Group:
+                # calib/search.py:933-942: the Group branch falls through into the final else
+                raise ValueError(f"Unknown granularity {self.granularity}")
+            scorer = self._acts_tensor_scorer(cache, batches, view)
+        else:
+            assert self.objective == SearchBasedCalibObjective.OutputsError
+            scorer = self._acts_outputs_scorer(mods, eval_inputs, eval_module, eval_kwargs, orig_wgts, orig_eval_inputs)
+        self.best_range, self.best_error = DynamicRange(), None
+        history = []
+        for iteration in self.ratios:
+            for ratio in iteration:
+                if self.is_clamp_based():
+                    candidate = self.base_range.scale(ratio=ratio, zero_domain=zd, is_float_point=is_fp)
+                else:
+                    candidate = DynamicRange(ratio=ratio)
+                error = scorer(candidate)
+                if record_errors:
+                    history.append(error.clone())
+                self._tell_general(error, candidate, ratio, device)
+        if record_errors:
+            self.candidate_errors = torch.stack(history)
+
+    def _acts_tensor_scorer(self, cache, batches: list[torch.Tensor], view: torch.Size):
+        """calib/search.py:928-946.  One launch of the error kernel per batch gives the float32 sums of every
+        (row, group); they are added up over the rows (and groups) in float64 and rounded once to the tensor's
+        dtype, where the reference's single multi-axis ``sum`` rounds once as well."""
+        fine = torch.Size([batches[0].shape[0], 1, *view[2:]])  # one row per group: the quantizer's own groups
+        degree = float(self.config.degree)
+        refs = [engine.canonical_groups(t, fine)[0] for t in batches]
+        channel_group = self.granularity == SearchBasedCalibGranularity.ChannelGroup
+
+        def score(candidate: DynamicRange) -> torch.Tensor:
+            total = None
+            for x, b2d in zip(batches, refs):
+                qx = self.quantizer.quantize(x, kernel=None, channels_dim=None, dynamic_range=candidate,
+                                             default_dtype=x.dtype, develop_dtype=self.develop_dtype).data
+                a2d, _ = engine.canonical_groups(qx, fine)
+                raw = engine.group_error(a2d, b2d, degree).view(fine[::2]).double()
+                if channel_group:
+                    e = raw.sum(dim=[d for d in range(raw.ndim) if d != 1]).view(self.error_shape)
+                else:
+                    e = raw.sum().view(1)
+                e = e.to(x.dtype)
+                total = e if total is None else total.add_(e)
+            return total
+
+        return score
+
+    def _acts_outputs_scorer(self, mods, eval_inputs: TensorsCache, eval_module: nn.Module, eval_kwargs: dict,
+                             orig_wgts, orig_eval_inputs):
+        """calib/search.py:902-918, 974-989 (inputs) and :1010-1073 (outputs): the evaluation module's outputs with
+        the candidate quantizer hooked onto ``mods`` (ahead of them for inputs, behind them for outputs) against its
+        outputs with nothing quantized (and the original weights in place); one float32 scalar per candidate."""
+        assert eval_inputs is not None, "eval_inputs should not be None when objective is OutputsError"
+        assert eval_module is not None and mods, "eval_module and the modules to hook are required"
+        ipts, orig_ipts = self._parse_ipts(eval_inputs), self._parse_ipts(orig_eval_inputs)
+        degree = float(self.config.degree)
+        is_output = self.tensor_type == TensorType.Outputs
+
+        def forward(cache: TensorsCache, index: int) -> torch.Tensor:
+            ipt = cache.extract(index, eval_kwargs)
+            y = eval_module(*ipt.args, **ipt.kwargs)
+            y = y[0] if not isinstance(y, torch.Tensor) else y
+            assert isinstance(y, torch.Tensor), "eval_mod should return a tensor"
+            return y.contiguous().view(-1, y.shape[-1])
+
+        saved = [(p, p.data) for p, _ in orig_wgts]
+        for p, ow in orig_wgts:
+            p.data = ow.to(device=p.data.device)
+        ref = orig_ipts or ipts
+        base = [forward(ref, i) for i in range(len(ref.front().data))]
+        for p, ow in saved:
+            p.data = ow
+
+        def score(candidate: DynamicRange) -> torch.Tensor:
+            def process(t: torch.Tensor) -> torch.Tensor:
+                return self.quantizer.quantize(t, kernel=None, dynamic_range=candidate, default_dtype=t.dtype,
+                                               develop_dtype=self.develop_dtype).data
+
+            hook = self.quantizer.as_hook(process, is_output=is_output).register(mods)
+            try:
+                total = None
+                for i, y0 in enumerate(base):
+                    e = engine.product_error(forward(ipts, i), y0, degree).double().sum().to(torch.float32).view(1)
+                    total = e if total is None else total.add_(e)
+            finally:
+                hook.remove()
+            return total
+
+        return score
+
+
+def _device_of(cache, mods, eval_module) -> torch.device:
+    """Where an activation search runs: the GPU the cached batches live on, else the one the modules live on."""
+    for t in cache.data:
+        if t.is_cuda:
+            return t.device
+    for m in list(mods or []) + ([eval_module] if eval_module is not None else []):
+        for p in m.parameters():
+            if p.is_cuda:
+                return p.device
+    dev = torch.device(cache.orig_device)
+    return dev if dev.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
 
 
 def q_zero_domain(quantizer: Quantizer):
@@ -392,12 +556,22 @@ def calibrate_dynamic_range(tensor_type: TensorType, config: DynamicRangeCalibCo
                 eval_inputs = activations
         else:
             assert eval_inputs is not None, "eval_inputs is required when eval_module is provided"
-    search_args = dict(x_acts=activations, x_mods=list(modules), eval_inputs=eval_inputs, eval_module=eval_module,
-                       eval_kwargs=eval_kwargs, orig_x_wgts=orig_weights, orig_x_acts=orig_activations,
-                       orig_eval_inputs=orig_eval_inputs)
+    else:
+        assert activations is not None, "activations is required for activation quantization calibration"
+        assert activations.num_tensors == 1, "only one tensor is supported for activation quantization calibration"
+    if tensor_type != TensorType.Outputs:
+        search_args = dict(x_acts=activations, x_mods=list(modules), eval_inputs=eval_inputs, eval_module=eval_module,
+                           eval_kwargs=eval_kwargs, orig_x_wgts=orig_weights, orig_x_acts=orig_activations,
+                           orig_eval_inputs=orig_eval_inputs)
+        x_wgts = list(weights)
+    else:
+        search_args = dict(y_wgts=list(weights), y_acts=activations, y_mods=list(modules), eval_inputs=eval_inputs,
+                           eval_module=eval_module, eval_kwargs=eval_kwargs, orig_y_wgts=orig_weights,
+                           orig_y_acts=orig_activations, orig_eval_inputs=orig_eval_inputs)
+        x_wgts = []
     if num_steps == 1:
         calibrator = DynamicRangeCalibrator(tensor_type=tensor_type, config=config, static=static, quantizer=quantizer)
-        return (calibrator.calibrate(x_wgts=list(weights), **search_args),)
+        return (calibrator.calibrate(x_wgts=x_wgts, **search_args),)
     # progressive quantizer: one calibrator per step, each seeing the tensor divided by the scales found so far
     if tensor_type != TensorType.Weights:
         raise NotImplementedError("progressive range search is implemented for weights only")

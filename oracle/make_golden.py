@@ -876,11 +876,147 @@ def gen_smooth_lowrank(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+class ToyGated(torch.nn.Module):
+    """up(x) * sigmoid(gate(x)) -> down: the evaluation module of the activation range fixtures (``up`` and ``gate``
+    share their input; ``mid`` is the identity whose output feeds ``down``)."""
+
+    def __init__(self, channels: int, hidden: int):
+        super().__init__()
+        nn = torch.nn
+        self.up = nn.Linear(channels, hidden, bias=False)
+        self.gate = nn.Linear(channels, hidden, bias=False)
+        self.mid = nn.Identity()
+        self.down = nn.Linear(hidden, channels, bias=False)
+
+    def forward(self, x):
+        return self.down(self.mid(self.up(x) * torch.sigmoid(self.gate(x))))
+
+
+RANGE_ACTS_CASES = {
+    "sint8_tnsr": dict(dtype="sint8", zero=None, groups=((-1, -1),), sdt=("f16",)),
+    "sint8_tnsr_defs": dict(dtype="sint8", zero=None, groups=((-1, -1),), sdt=(None,)),
+    "uint4_post_g32": dict(dtype="uint4", zero="PostScale", groups=((1, 32),), sdt=("f16",)),
+    "sint4_g32": dict(dtype="sint4", zero=None, groups=((1, 32),), sdt=("f16",)),
+    "uint8_pre_tnsr": dict(dtype="uint8", zero="PreScale", groups=((-1, -1),), sdt=("f16",)),
+    "sint8_token": dict(dtype="sint8", zero=None, groups=((1, -1),), sdt=("f16",)),
+}
+
+
+@torch.no_grad()
+def gen_range_acts(ref) -> None:
+    """Range search of activations (calib/range.py:101-150, calib/search.py:839-1078): static ranges of a module's
+    inputs scored on the tensor itself or on an evaluation module's outputs, static ranges of a module's outputs,
+    and the clamp / ratio search of dynamically quantized inputs."""
+    from deepcompressor.calib.config import (
+        DynamicRangeCalibConfig,
+        SearchBasedCalibGranularity,
+        SearchBasedCalibObjective,
+        SearchBasedCalibStrategy,
+    )
+    from deepcompressor.calib.range import DynamicRangeCalibrator, calibrate_dynamic_range
+    from deepcompressor.data.cache import TensorCache, TensorsCache
+    from deepcompressor.data.common import TensorType
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+
+    arrays, meta = {}, {}
+    records: list[dict] = []
+    orig_tell = DynamicRangeCalibrator._tell
+
+    def tell(self, error, _orig=orig_tell):
+        if not records or records[-1]["owner"] is not self:
+            records.append(dict(owner=self, errors=[]))
+        records[-1]["errors"].append(_np(error[0]).copy())
+        _orig(self, error)
+
+    DynamicRangeCalibrator._tell = tell
+    try:
+        # (quantizer case, dtype, tensor type, objective, granularity, strategy, static, allow_scale, degree, grids)
+        plan = [
+            ("sint8_tnsr", "bf16", "Inputs", "TensorError", "Group", "GridSearch", True, False, 2, 20),
+            ("uint4_post_g32", "f16", "Inputs", "TensorError", "Group", "GridSearch", True, False, 2.4, 20),
+            ("sint4_g32", "bf16", "Inputs", "TensorError", "ChannelGroup", "GridSearch", True, False, 2, 20),
+            ("uint4_post_g32", "bf16", "Inputs", "TensorError", "Layer", "GridSearch", True, False, 2, 20),
+            ("sint8_tnsr", "f32", "Inputs", "OutputsError", "Layer", "GridSearch", True, False, 2, 20),
+            ("uint8_pre_tnsr", "bf16", "Inputs", "OutputsError", "Layer", "GridSearch", True, False, 2, 12),
+            ("sint8_tnsr_defs", "f16", "Outputs", "OutputsError", "Layer", "Manual", True, False, 2, 20),
+            ("sint8_tnsr", "f32", "Outputs", "OutputsError", "Layer", "GridSearch", True, False, 2, 20),
+            ("uint4_post_g32", "f32", "Outputs", "TensorError", "Group", "GridSearch", True, False, 2, 12),
+            ("sint8_token", "f32", "Inputs", "OutputsError", "Layer", "GridSearch", False, False, 2, 12),
+            ("sint8_token", "f32", "Inputs", "OutputsError", "Layer", "GridSearch", False, True, 2, 12),
+            ("sint4_g32", "bf16", "Inputs", "TensorError", "Layer", "GridSearch", False, True, 2, 12),
+        ]
+        channels, hidden = 64, 96
+        for idx, (cname, dt, ttype, objective, gran, strategy, static, allow_scale, degree, grids) in enumerate(plan):
+            case = RANGE_ACTS_CASES[cname]
+            g = torch.Generator().manual_seed(5000 + idx)
+            tdt = TORCH_DT[dt]
+            mod = ToyGated(channels, hidden).to(tdt)
+            for lin in (mod.up, mod.gate, mod.down):
+                lin.weight.data = (torch.randn(lin.weight.shape, generator=g) * 0.15).to(tdt)
+            gains = torch.exp(torch.randn(channels, generator=g) * 0.8)
+            xs = [(torch.randn(2, 12, channels, generator=g) * gains).to(tdt) for _ in range(3)]
+            xs[1][0, 3, 5] = xs[1].abs().max() * 3  # an outlier, so that clipping pays
+            cache = lambda data: TensorsCache(TensorCache([d.clone() for d in data], channels_dim=-1,  # noqa: E731
+                                                          reshape=LinearReshapeFn(), num_cached=3, num_total=3,
+                                                          num_samples=6))
+            q = _build_quantizer(ref, case)
+            q.channels_dim = -1
+            cfg = DynamicRangeCalibConfig(
+                degree=degree, objective=SearchBasedCalibObjective[objective],
+                strategy=SearchBasedCalibStrategy[strategy], granularity=SearchBasedCalibGranularity[gran],
+                max_shrink=0.4, max_expand=1.0, num_grids=grids, allow_scale=allow_scale,
+                element_batch_size=-1, element_size=-1, sample_batch_size=-1, sample_size=-1,
+            )
+            if ttype == "Inputs":
+                modules, acts = [mod.up, mod.gate], cache(xs)
+            else:
+                modules = [mod.mid]
+                acts = cache([mod.up(x) * torch.sigmoid(mod.gate(x)) for x in xs])
+            tag = f"{idx}|{cname}|{dt}|{ttype}|{objective}|{gran}|{strategy}|static{int(static)}|scale{int(allow_scale)}"
+            records.clear()
+            raised = None
+            try:
+                with torch.inference_mode():
+                    ranges = calibrate_dynamic_range(TensorType[ttype], cfg, static, q, modules, acts,
+                                                     eval_inputs=cache(xs), eval_module=mod, eval_kwargs={})
+            except (RuntimeError, ValueError, AssertionError) as exc:
+                raised, ranges = (str(exc).splitlines() or [type(exc).__name__])[0][:200], ()
+            for name in ("up", "gate", "down"):
+                arrays[f"{tag}|w_{name}"] = _np(getattr(mod, name).weight.data)
+            for i, x in enumerate(xs):
+                arrays[f"{tag}|x{i}"] = _np(x)
+            arrays[f"{tag}|ratios"] = np.asarray([r for it in cfg.get_ratios() for r in it], dtype=np.float64)
+            for step, (rng, rec) in enumerate(zip(ranges or (), records)):
+                if rng.max is not None:
+                    arrays[f"{tag}|s{step}|max"] = _np(rng.max)
+                if isinstance(rng.min, torch.Tensor):
+                    arrays[f"{tag}|s{step}|min"] = _np(rng.min)
+                if isinstance(rng.ratio, torch.Tensor):
+                    arrays[f"{tag}|s{step}|out_ratio"] = _np(rng.ratio)
+                arrays[f"{tag}|s{step}|ratio"] = _np(rec["owner"].best_range.ratio)
+                arrays[f"{tag}|s{step}|best_error"] = _np(rec["owner"].best_error)
+                arrays[f"{tag}|s{step}|errors"] = np.stack(rec["errors"])
+            if raised is not None and records:
+                arrays[f"{tag}|s0|errors"] = np.stack(records[0]["errors"])
+            meta[tag] = dict(case=cname, in_dtype=dt, tensor_type=ttype, objective=objective, granularity=gran,
+                             strategy=strategy, static=static, allow_scale=allow_scale, degree=degree, num_grids=grids,
+                             channels=channels, hidden=hidden, num_steps=len(ranges or ()), reference_raised=raised,
+                             out_ratio_is_float=bool(ranges) and isinstance(ranges[0].ratio, float),
+                             resolved_objective=records[0]["owner"].objective.name if records else None,
+                             resolved_granularity=records[0]["owner"].granularity.name if records else None)
+            print(" ", tag, "->", raised or "ok")
+    finally:
+        DynamicRangeCalibrator._tell = orig_tell
+    np.savez_compressed(os.path.join(OUT, "range_acts.npz"), **arrays)
+    with open(os.path.join(OUT, "range_acts.json"), "w") as f:
+        json.dump(dict(cases=RANGE_ACTS_CASES, entries=meta), f, indent=1)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
