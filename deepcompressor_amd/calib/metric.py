@@ -3,7 +3,7 @@
 Same static methods as the reference's ``ChannelMetric``.  A tensor is viewed as [N, num_channels, -1] and reduced
 over the first and last axes by ``dcq_channel_metric`` (one pass, HBM-bound); lists of tensors accumulate into the
 same output, which is what the reference's maximum / sum over the per-tensor results amounts to.
-``abs_normalize_mean`` (normalisation by the per-group maximum first) is not implemented.
+``abs_normalize_mean`` first divides every value by the largest magnitude of its group (``dcq_group_range``).
 """
 
 from __future__ import annotations
@@ -70,7 +70,20 @@ class ChannelMetric:
     @staticmethod
     def abs_normalize_mean(tensors, num_channels: int, group_shape: tp.Sequence[int], device=None,
                            dtype: torch.dtype = torch.float32) -> torch.Tensor:
-        raise NotImplementedError("abs_normalize_mean (metric.py:169-181) is not implemented")
+        """mean |T[:, c, :]| / max |group| with groups of ``group_shape`` (metric.py:16-30, 169-181)."""
+        from ..data.range import _group_min_max
+        from ..data.utils.shape import infer_view_shape
+
+        normalized = []
+        for t in _as_list(tensors):
+            if not t.is_cuda:
+                t = t.to(device if device is not None and torch.device(device).type == "cuda" else "cuda")
+            view = t.contiguous().view(infer_view_shape(t.shape, group_shape)).to(dtype)
+            vmax, _ = _group_min_max(view, with_min=False)
+            vmax = torch.where(vmax == 0, torch.ones_like(vmax), vmax).to(dtype)
+            normalized.append((view / vmax).view(t.shape))
+        total, count = _reduce(normalized, num_channels, _ABS_SUM, device, dtype)
+        return total.div_(count)
 
     @staticmethod
     def root_mean_square(tensors: tp.Iterable[torch.Tensor] | torch.Tensor, num_channels: int,

@@ -1012,11 +1012,113 @@ def gen_range_acts(ref) -> None:
         json.dump(dict(cases=RANGE_ACTS_CASES, entries=meta), f, indent=1)
 
 
+@torch.no_grad()
+def gen_reorder(ref) -> None:
+    """Channel reordering (deepcompressor/calib/reorder.py:61-540): every channel metric, both index modes, heads
+    with and without repeats, and the calibrator (Manual as QoQ runs it, GridSearch over every metric / index mode)
+    on a linear and on the gated toy module."""
+    import torch.nn as nn
+    from deepcompressor.calib import reorder as rr
+    from deepcompressor.calib.config import SearchBasedCalibStrategy
+    from deepcompressor.calib.config.reorder import ChannelOrderCalibConfig
+    from deepcompressor.calib.metric import ChannelMetric
+    from deepcompressor.data.cache import TensorCache, TensorsCache
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+
+    arrays, meta = {}, {}
+    g = torch.Generator().manual_seed(9191)
+    channels = 64
+    gains = torch.exp(torch.randn(channels, generator=g))
+    xs = [torch.randn(2, 10, channels, generator=g) * gains for _ in range(3)]
+    ws = [torch.randn(48, channels, generator=g) * 0.1 * torch.exp(0.5 * torch.randn(channels, generator=g)),
+          torch.randn(24, channels, generator=g) * 0.1]
+    cache = lambda data: TensorsCache(TensorCache([d.clone() for d in data], channels_dim=-1,  # noqa: E731
+                                                  reshape=LinearReshapeFn(), num_cached=3, num_total=3, num_samples=6))
+    for i, x in enumerate(xs):
+        arrays[f"x{i}"] = x.numpy().copy()
+    for i, w in enumerate(ws):
+        arrays[f"w{i}"] = w.numpy().copy()
+    # --- metrics and the orders they give
+    for mode in ChannelOrderCalibConfig.ChannelMetric:
+        for heads in (1, 4):
+            arrays[f"metric|{mode.name}|h{heads}"] = rr.get_channel_metric(cache(xs), ws, mode, channels,
+                                                                           num_heads=heads).numpy().copy()
+    arrays["metric|abs_normalize_mean|h4"] = ChannelMetric.abs_normalize_mean(
+        [x.view(-1, channels) for x in xs], channels, [-1, channels // 4]).numpy().copy()
+    metric = torch.from_numpy(arrays["metric|InputsAbsMax|h1"])
+    index_cases = {}
+    for imode in ChannelOrderCalibConfig.ChannelIndex:
+        for heads, repeats in ((1, 1), (4, 1), (4, 2)):
+            for mmode in ("InputsAbsMax", "InputsAbsMean"):
+                key = f"index|{mmode}|{imode.name}|h{heads}|r{repeats}"
+                arrays[key] = rr.init_channel_index_from_metric(
+                    torch.from_numpy(arrays[f"metric|{mmode}|h1"]), ChannelOrderCalibConfig.ChannelMetric[mmode], imode,
+                    group_size=16, num_heads=heads, num_head_repeats=repeats).numpy().copy()
+                index_cases[key] = dict(metric=mmode, index_mode=imode.name, heads=heads, repeats=repeats, group_size=16)
+    meta["index_cases"] = index_cases
+    # --- the calibrator
+    def quantizers(small: bool):
+        # with heads, channels only move inside their head (16 channels): groups of 8 so that the order matters
+        case_w = dict(dtype="uint4", zero="PostScale", groups=((1, 8 if small else 16),), sdt=("f16",))
+        case_x = dict(dtype="sint8", zero=None, groups=((1, 8 if small else 32),), sdt=("f16",))
+        wq, xq = _build_quantizer(ref, case_w), _build_quantizer(ref, case_x)
+        xq.channels_dim = -1
+        return wq, xq, case_w, case_x
+
+    runs = {}
+    for tag, strategy, module_kind, heads, repeats in (("manual_linear", "Manual", "linear", 1, 1),
+                                                       ("search_linear", "GridSearch", "linear", 1, 1),
+                                                       ("search_linear_heads", "GridSearch", "linear", 4, 2),
+                                                       ("search_gated", "GridSearch", "gated", 1, 1)):
+        wq, xq, case_w, case_x = quantizers(heads > 1)
+        cfg = ChannelOrderCalibConfig(strategy=SearchBasedCalibStrategy[strategy],
+                                      channel_metric=ChannelOrderCalibConfig.ChannelMetric.InputsAbsMax,
+                                      channel_index=ChannelOrderCalibConfig.ChannelIndex.Sequential)
+        calib = rr.ChannelOrderCalibrator(cfg, wq, xq, num_heads=heads, num_head_repeats=repeats)
+        stats = []
+        orig_tell = calib._tell
+
+        def spy(errors, _orig=orig_tell, _calib=calib, _stats=stats):
+            _orig(errors)
+            _stats.append(float(errors[0][0]))
+
+        calib._tell = spy
+        if module_kind == "linear":
+            lin = nn.Linear(channels, 48, bias=False)
+            lin.weight.data = ws[0].clone()
+            best = calib.calibrate(x_wgts=[lin.weight], x_acts=cache(xs), x_mods=[lin], eval_inputs=cache(xs),
+                                   eval_module=lin, reorder_wgts=[(lin.weight, 1)], reorder_ipt_mods=[(lin, -1, None)],
+                                   reorder_opt_mods=[])
+            assert torch.equal(lin.weight.data, ws[0])
+        else:
+            mod = ToyGated(channels, 48)
+            mod.up.weight.data, mod.gate.weight.data = ws[0].clone(), (ws[0] * 0.5 + 0.01).clone()
+            mod.down.weight.data = torch.randn(channels, 48, generator=g) * 0.1
+            arrays[f"{tag}|w_down"] = mod.down.weight.data.numpy().copy()
+            best = calib.calibrate(x_wgts=[mod.up.weight, mod.gate.weight], x_acts=cache(xs), x_mods=[mod.up, mod.gate],
+                                   eval_inputs=cache(xs), eval_module=mod, eval_kwargs={},
+                                   reorder_wgts=[(mod.up.weight, 1), (mod.gate.weight, 1)],
+                                   reorder_ipt_mods=[(mod, -1, None)], reorder_opt_mods=[])
+        arrays[f"{tag}|errors"] = np.asarray(stats, dtype=np.float64)
+        arrays[f"{tag}|best"] = (best.numpy().copy() if best is not None else np.zeros(0, dtype=np.int64))
+        for i, idx in enumerate(calib.channel_indexes):
+            arrays[f"{tag}|cand{i}"] = idx.numpy().copy() if idx is not None else np.zeros(0, dtype=np.int64)
+        runs[tag] = dict(strategy=strategy, module=module_kind, heads=heads, repeats=repeats, case_w=case_w,
+                         case_x=case_x, group_size=min(case_w["groups"][0][1], case_x["groups"][0][1]), best_candidate_id=int(calib.best_candidate_id), best_is_identity=best is None,
+                         num_candidates=len(stats), best_error=[float(v) for v in calib.best_error])
+        print(" ", tag, "best", calib.best_candidate_id, "of", len(stats))
+    meta["runs"] = runs
+    meta["channels"] = channels
+    np.savez_compressed(os.path.join(OUT, "reorder.npz"), **arrays)
+    with open(os.path.join(OUT, "reorder.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
