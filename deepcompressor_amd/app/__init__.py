@@ -1,0 +1,11 @@
+"""Callers of the hot path that own its data formats: the per-layer weight / activation stages and the checkpoint
+files they leave behind.  Model loading, datasets, evaluation and the CLI of the reference's ``app`` package are
+not part of this package."""
+
+from .llm import (LinearEntry, LlmActivationQuantizer, LlmActivationQuantizerConfig, LlmQuantizer, LlmQuantizerConfig,
+                  LlmWeightQuantizer, LlmWeightQuantizerConfig, load_weight_checkpoint, quantize_layer_weights,
+                  save_weight_checkpoint)
+
+__all__ = ["LinearEntry", "LlmActivationQuantizer", "LlmActivationQuantizerConfig", "LlmQuantizer", "LlmQuantizerConfig",
+           "LlmWeightQuantizer", "LlmWeightQuantizerConfig", "load_weight_checkpoint", "quantize_layer_weights",
+           "save_weight_checkpoint"]

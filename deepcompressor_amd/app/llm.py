@@ -1,0 +1,236 @@
+"""Per-layer weight quantization stage and its checkpoint files
+(reference: deepcompressor/app/llm/quant/quantizer/{config,quantizer}.py, app/llm/quant/weight.py:24-105,
+app/llm/ptq.py:228-266).
+
+The reference walks a transformer block through its module-struct classes; here a layer is a plain list of
+:class:`LinearEntry` (key, name, module, evaluation module), so any caller that can name its linears can run the
+stage.  What it leaves behind is laid out as the reference's files are:
+
+* ``wgts.pt``  -- ``{module_name: Quantizer.state_dict()}`` (the calibrated ranges; reloadable),
+* ``scale.pt`` -- ``{param}.scale.{level}`` for every scale level across progressive steps, and ``{param}.zero``
+  (zero point in the integer domain) or ``{param}.scaled_zero`` (zero point after scaling),
+* ``model.pt`` -- the dequantized weights (``state_dict`` of the module).
+"""
+
+from __future__ import annotations
+
+import os
+import typing as tp
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn as nn
+
+from ..calib.config.range import SkipBasedDynamicRangeCalibConfig
+from ..calib.range import calibrate_dynamic_range
+from ..data.cache import IOTensorsCache, TensorsCache
+from ..data.common import TensorType
+from ..data.range import DynamicRange
+from ..data.zero import ZeroPointDomain
+from ..quantizer.config.base import ProgressiveQuantizerConfig
+from ..quantizer.kernel.gptq import QuantGptqConfig
+from ..quantizer.processor import Quantizer
+from ..utils.config import SkipBasedConfig, configclass
+
+__all__ = ["LlmQuantizerConfig", "LlmWeightQuantizerConfig", "LlmActivationQuantizerConfig", "LlmQuantizer",
+           "LlmWeightQuantizer", "LlmActivationQuantizer", "LinearEntry", "quantize_layer_weights",
+           "save_weight_checkpoint", "load_weight_checkpoint"]
+
+
+@configclass
+@dataclass
+class LlmQuantizerConfig(SkipBasedConfig, ProgressiveQuantizerConfig):
+    """app/llm/quant/quantizer/config.py:18-98: a (progressive) quantizer plus whether its range is static, the GPTQ
+    kernel and the range calibration."""
+
+    static: bool = False
+    kernel_gptq: QuantGptqConfig | None = None
+    calib_range: SkipBasedDynamicRangeCalibConfig | None = None
+
+    def __post_init__(self) -> None:
+        super().__post_init__()
+        if self.quant_dtype is None:
+            self.static, self.kernel_gptq, self.calib_range = False, None, None
+        if self.static and self.calib_range is None:
+            self.calib_range = SkipBasedDynamicRangeCalibConfig()
+
+    @property
+    def enabled_gptq(self) -> bool:
+        return self.kernel_gptq is not None
+
+    @property
+    def enabled_calib_range(self) -> bool:
+        return self.calib_range is not None
+
+    @property
+    def needs_calib_data(self) -> bool:
+        return self.enabled_calib_range and (self.calib_range.needs_search or self.static)
+
+    def generate_calib_dirname(self) -> str:
+        name = ""
+        if self.static:
+            name += ".static"
+        if self.enabled_gptq:
+            name += ".gptq"
+        if self.enabled_calib_range and (self.calib_range.needs_search or self.calib_range.ratio != 1):
+            name += ".range"
+        return name[1:] if name else ""
+
+
+@configclass
+@dataclass
+class LlmWeightQuantizerConfig(LlmQuantizerConfig):
+    """Weights are always quantized statically (config.py:101-124)."""
+
+    static: bool = field(init=False, default=True)
+
+    @property
+    def needs_calib_data(self) -> bool:
+        return self.enabled_calib_range and self.calib_range.needs_search
+
+
+@configclass
+@dataclass
+class LlmActivationQuantizerConfig(LlmQuantizerConfig):
+    """Activations never take the GPTQ kernel (config.py:127-160)."""
+
+    kernel_gptq: None = field(init=False, default=None)
+
+
+@dataclass
+class LlmQuantizer(Quantizer):
+    """quantizer.py:22-129: a Quantizer that takes its kernel and its range calibration from its config."""
+
+    config: LlmQuantizerConfig = None
+    tensor_type: TensorType = TensorType.Weights
+
+    def __post_init__(self) -> None:
+        self.kernel = self.config.kernel_gptq
+
+    def calibrate_dynamic_range(self, modules: tp.Sequence[nn.Module], activations: TensorsCache,
+                                weights: tp.Sequence[nn.Parameter] | None = None,
+                                eval_inputs: TensorsCache | None = None, eval_module: nn.Module | None = None,
+                                eval_kwargs: dict[str, tp.Any] | None = None, orig_weights=None, orig_activations=None,
+                                orig_eval_inputs=None) -> tp.Sequence[DynamicRange] | None:
+        if (not self.is_enabled() or self.config.calib_range is None
+                or not self.config.calib_range.is_enabled_for(self.key)):
+            self.dynamic_range = None
+        else:
+            self.dynamic_range = calibrate_dynamic_range(
+                tensor_type=self.tensor_type, config=self.config.calib_range, static=self.config.static, quantizer=self,
+                modules=modules, activations=activations, weights=weights, eval_inputs=eval_inputs,
+                eval_module=eval_module, eval_kwargs=eval_kwargs, orig_weights=orig_weights,
+                orig_activations=orig_activations, orig_eval_inputs=orig_eval_inputs)
+        return self.dynamic_range
+
+
+@dataclass
+class LlmWeightQuantizer(LlmQuantizer):
+    """quantizer.py:132-215."""
+
+    config: LlmWeightQuantizerConfig = None
+    channels_dim: None = field(init=False, default=None)
+    tensor_type: TensorType = field(init=False, default=TensorType.Weights)
+
+    def calibrate_dynamic_range(self, module: nn.Module, inputs: TensorsCache, weight: nn.Parameter | None = None,
+                                eval_inputs: TensorsCache | None = None, eval_module: nn.Module | None = None,
+                                eval_kwargs: dict[str, tp.Any] | None = None, orig_inputs: TensorsCache | None = None,
+                                orig_eval_inputs: TensorsCache | None = None):
+        return super().calibrate_dynamic_range(
+            modules=[module], weights=[weight] if weight is not None else [module.weight], activations=inputs,
+            eval_inputs=eval_inputs, eval_module=eval_module, eval_kwargs=eval_kwargs, orig_activations=orig_inputs,
+            orig_eval_inputs=orig_eval_inputs)
+
+
+@dataclass
+class LlmActivationQuantizer(LlmQuantizer):
+    """quantizer.py:218-258: inputs or outputs of a module, channels on ``channels_dim``."""
+
+    config: LlmActivationQuantizerConfig = None
+    tensor_type: TensorType = TensorType.Inputs
+
+    def __post_init__(self) -> None:
+        super().__post_init__()
+        assert self.tensor_type != TensorType.Weights, "The tensor type cannot be weights."
+        assert isinstance(self.channels_dim, int), "The channels dimension must be provided."
+
+
+@dataclass
+class LinearEntry:
+    """One linear of a layer: ``key`` selects per-kind settings (qkv_proj, out_proj, up_proj, down_proj ...), ``name``
+    is its path in the model (checkpoint keys derive from it).  ``eval_*``: the module whose outputs score range
+    candidates and the name its inputs are cached under; default: the linear itself (the reference scores q_proj /
+    k_proj on their whole attention block, weight.py:60-64)."""
+
+    key: str
+    name: str
+    module: nn.Linear
+    eval_name: str | None = None
+    eval_module: nn.Module | None = None
+    eval_kwargs: dict[str, tp.Any] | None = None
+
+
+@torch.inference_mode()
+def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQuantizerConfig,
+                           quantizer_state_dict: dict[str, tp.Any],
+                           layer_cache: dict[str, IOTensorsCache] | None = None,
+                           return_with_scale_state_dict: bool = False, develop_dtype: torch.dtype = torch.float32
+                           ) -> dict[str, torch.Tensor | float | None]:
+    """app/llm/quant/weight.py:24-105.  Pass 1 calibrates the range of every linear that has no entry in
+    ``quantizer_state_dict`` yet (and stores it there); pass 2 reloads each range, quantizes the weight with the
+    configured kernel (GPTQ when set, fed by the linear's cached inputs) and writes the dequantized weight back into
+    the module.  Returns the scale state dict when asked for."""
+    layer_cache = layer_cache or {}
+    for e in entries:
+        assert isinstance(e.module, nn.Linear)
+        quantizer = LlmWeightQuantizer(config, develop_dtype=develop_dtype, key=e.key)
+        if quantizer.is_enabled() and e.name not in quantizer_state_dict:
+            eval_name = e.eval_name or e.name
+            quantizer.calibrate_dynamic_range(
+                module=e.module, inputs=layer_cache[e.name].inputs if layer_cache else None,
+                eval_inputs=layer_cache[eval_name].inputs if layer_cache else None,
+                # without cached activations only a search on the weight itself can run: no evaluation module then
+                eval_module=(e.eval_module or e.module) if layer_cache else None, eval_kwargs=e.eval_kwargs)
+            quantizer_state_dict[e.name] = quantizer.state_dict()
+    scale_state_dict: dict[str, torch.Tensor | float | None] = {}
+    for e in entries:
+        quantizer = LlmWeightQuantizer(config, develop_dtype=develop_dtype, key=e.key)
+        if not quantizer.is_enabled():
+            continue
+        param_name = f"{e.name}.weight"
+        quantizer.load_state_dict(quantizer_state_dict[e.name], device=e.module.weight.device)
+        result = quantizer.quantize(e.module.weight.data,
+                                    inputs=layer_cache[e.name].inputs.front() if layer_cache else None,
+                                    return_with_dequant=True, return_with_quant=return_with_scale_state_dict)
+        e.module.weight.data = result.data
+        if return_with_scale_state_dict:
+            scale_state_dict.update(result.scale.state_dict(f"{param_name}.scale"))
+            zero_name = "scaled_zero" if config.zero_domain is ZeroPointDomain.PostScale else "zero"
+            zero = result.zero
+            scale_state_dict[f"{param_name}.{zero_name}"] = zero.to("cpu") if isinstance(zero, torch.Tensor) else zero
+    return scale_state_dict
+
+
+def save_weight_checkpoint(dirpath: str, *, quantizer_state_dict: dict[str, tp.Any] | None = None,
+                           scale_state_dict: dict[str, tp.Any] | None = None,
+                           model_state_dict: dict[str, torch.Tensor] | None = None) -> dict[str, str]:
+    """Write ``wgts.pt`` / ``scale.pt`` / ``model.pt`` into ``dirpath`` as app/llm/ptq.py:251-266 does; returns the
+    paths written."""
+    os.makedirs(dirpath, exist_ok=True)
+    written = {}
+    for fname, obj in (("wgts.pt", quantizer_state_dict), ("scale.pt", scale_state_dict), ("model.pt", model_state_dict)):
+        if obj is not None:
+            path = os.path.join(dirpath, fname)
+            torch.save(obj, path)
+            written[fname] = path
+    return written
+
+
+def load_weight_checkpoint(dirpath: str) -> dict[str, tp.Any]:
+    """Whatever of ``wgts.pt`` / ``scale.pt`` / ``model.pt`` exists in ``dirpath`` (tensor-only files)."""
+    out = {}
+    for fname in ("wgts.pt", "scale.pt", "model.pt"):
+        path = os.path.join(dirpath, fname)
+        if os.path.exists(path):
+            out[fname] = torch.load(path, weights_only=True)
+    return out

@@ -157,8 +157,8 @@ class DynamicRangeCalibrator:
         for s in self.view_shape[1::2]:
             group_size *= s
         fused = (self.pre_scale is None and info.num_steps == 1 and info.steps[0].scale.is_single_level()
-                 and tuple(info.steps[0].tensor_view_shape) == tuple(self.view_shape) and group_size <= 512
-                 and group_size % (8 if w.dtype == torch.float32 else 16) == 0
+                 and tuple(info.steps[0].tensor_view_shape) == tuple(self.view_shape)
+                 and group_size in (16, 32, 64, 128, 256, 512)  # the team sizes the fused kernel is built for
                  and not (q.range_bound is not None and q.range_bound.is_set()))
         self.path = "fused" if fused else "general"
         if fused:

@@ -120,9 +120,17 @@ def cached_hessian_key():
     return _state.hessian["key"]
 
 
+def _version_of(t: torch.Tensor) -> int:
+    """In-place modification counter; tensors made under ``torch.inference_mode`` keep none (0 then)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return 0
+
+
 def _inputs_key(inputs: TensorCache, device: torch.device):
     return (device, inputs.num_samples, inputs.channels_dim,
-            tuple((t.data_ptr(), tuple(t.shape), t.dtype, t._version) for t in inputs.data))
+            tuple((t.data_ptr(), tuple(t.shape), t.dtype, _version_of(t)) for t in inputs.data))
 
 
 def hessian_of(inputs: TensorCache, device: torch.device) -> torch.Tensor:
@@ -234,7 +242,7 @@ def cholesky_inverse_upper(hessian: torch.Tensor, perm: torch.Tensor | None, dia
 def _inverse_factor_of(hessian: torch.Tensor, config: QuantGptqConfig):
     """(dead channels, act-order permutation, its inverse, U) of a Hessian (gptq.py:199-233), memoised for the most
     recent Hessian tensor: weights that share their inputs share all four."""
-    key = (hessian._version, config.damp_percentage, config.num_inv_tries)
+    key = (_version_of(hessian), config.damp_percentage, config.num_inv_tries)
     _factor_cache = _state.factor
     hit = _factor_cache["key"]
     if hit is not None and hit[0] is hessian and hit[1] == key:

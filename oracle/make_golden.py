@@ -1114,11 +1114,90 @@ def gen_reorder(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+@torch.no_grad()
+def gen_llm_stage(ref) -> None:
+    """The per-layer weight stage as the reference's LLM app runs it (app/llm/quant/weight.py:57-103 with
+    LlmWeightQuantizer): calibrate -> Quantizer.state_dict -> reload -> quantize -> scale state dict.  RTN kernel (the
+    GPTQ kernel is covered by its own fixtures), GPTQ-R style range search and the QoQ progressive quantizer."""
+    import torch.nn as nn
+    from deepcompressor.app.llm.quant.quantizer.config import LlmWeightQuantizerConfig
+    from deepcompressor.app.llm.quant.quantizer.quantizer import LlmWeightQuantizer
+    from deepcompressor.calib.config import (
+        SearchBasedCalibGranularity,
+        SearchBasedCalibObjective,
+        SearchBasedCalibStrategy,
+        SkipBasedDynamicRangeCalibConfig,
+    )
+    from deepcompressor.data.cache import TensorCache, TensorsCache
+    from deepcompressor.data.dtype import QuantDataType
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+    from deepcompressor.data.zero import ZeroPointDomain
+
+    arrays, meta = {}, {}
+    plans = {
+        "gptq_r_rtn": dict(dtype="uint4", zero="PostScale", groups=((1, 128),), sdt=("f16",), search=True),
+        "qoq_g128": dict(dtype="uint4", zero="PostScale", groups=((1, -1), (1, 128)), sdt=("f16", "sint8"),
+                         inter=("sint8",), levels=(0,), search=False),
+        "qoq_gchn_pre": dict(dtype="sint4", zero="PreScale", groups=((1, -1),), sdt=("f16",), search=True, skip="k_proj"),
+    }
+    g = torch.Generator().manual_seed(31337)
+    names = [("q_proj", "layers.0.attn.q_proj", (64, 256)), ("k_proj", "layers.0.attn.k_proj", (32, 256)),
+             ("down_proj", "layers.0.mlp.down_proj", (48, 384))]
+    for tag, c in plans.items():
+        def sd(x):
+            return None if x is None else (TORCH_DT[x] if x in TORCH_DT else QuantDataType.from_str(x))
+
+        calib = SkipBasedDynamicRangeCalibConfig(
+            degree=2.4, objective=SearchBasedCalibObjective.TensorError, strategy=SearchBasedCalibStrategy.GridSearch,
+            granularity=SearchBasedCalibGranularity.Group, max_shrink=0.2, max_expand=1.0, num_grids=20,
+            skips=[c["skip"]] if c.get("skip") else []) if c["search"] else None
+        kw = dict(dtype=QuantDataType.from_str(c["dtype"]), zero_point=ZeroPointDomain[c["zero"]],
+                  group_shapes=c["groups"], scale_dtypes=tuple(sd(x) for x in c["sdt"]), calib_range=calib)
+        if "inter" in c:
+            kw.update(intermediate_dtypes=tuple(QuantDataType.from_str(x) for x in c["inter"]),
+                      intermediate_levels=c["levels"])
+        config = LlmWeightQuantizerConfig(**kw)
+        meta[tag] = dict(case={k: v for k, v in c.items()}, calib_dirname=config.generate_calib_dirname(),
+                         dirnames=config.generate_dirnames(prefix="w"), modules=[])
+        scale_state_dict = {}
+        for key, name, shape in names:
+            w = _mk_input(shape, "f16", seed=int(torch.randint(0, 10 ** 6, (1,), generator=g)))
+            lin = nn.Linear(shape[1], shape[0], bias=False).to(torch.float16)
+            lin.weight = nn.Parameter(w.clone(), requires_grad=False)
+            dummy = TensorsCache(TensorCache([torch.zeros(1, 8, shape[1], dtype=torch.float16)], channels_dim=-1,
+                                             reshape=LinearReshapeFn()))
+            q = LlmWeightQuantizer(config, develop_dtype=torch.float32, key=key)
+            q.calibrate_dynamic_range(module=lin, inputs=dummy, eval_inputs=dummy, eval_module=lin)
+            state = q.state_dict()
+            q2 = LlmWeightQuantizer(config, develop_dtype=torch.float32, key=key)
+            q2.load_state_dict(state, device="cpu")
+            result = q2.quantize(lin.weight.data, inputs=None, return_with_dequant=True, return_with_quant=True)
+            arrays[f"{tag}|{name}|w"] = _np(w)
+            arrays[f"{tag}|{name}|dequant"] = _np(result.data)
+            entries = result.scale.state_dict(f"{name}.weight.scale")
+            zero_name = "scaled_zero" if config.zero_domain is ZeroPointDomain.PostScale else "zero"
+            entries[f"{name}.weight.{zero_name}"] = result.zero
+            for k, v in entries.items():
+                arrays[f"{tag}|sd|{k}"] = _np(v)
+            dyn = state["dynamic_range"]
+            dyn = (dyn,) if isinstance(dyn, dict) else (dyn or ())
+            for step, d in enumerate(dyn):
+                for part in ("min", "max"):
+                    if d is not None and isinstance(d.get(part), torch.Tensor):
+                        arrays[f"{tag}|{name}|range{step}|{part}"] = _np(d[part])
+            meta[tag]["modules"].append(dict(key=key, name=name, shape=list(shape), sd_keys=sorted(entries),
+                                             state_keys=sorted(state), num_ranges=len(dyn),
+                                             range_is_none=state["dynamic_range"] is None))
+    np.savez_compressed(os.path.join(OUT, "llm_stage.npz"), **arrays)
+    with open(os.path.join(OUT, "llm_stage.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)

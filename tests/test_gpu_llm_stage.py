@@ -1,0 +1,160 @@
+"""The per-layer weight stage and its checkpoint files on the GPU against fixtures captured from the reference's
+LlmWeightQuantizer flow, plus what the reference's QServe converter does with those files."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from _product import to_device, to_np
+from _stage import stage_config
+from conftest import assert_bit_equal, load_golden
+
+from deepcompressor_amd.app import (LinearEntry, load_weight_checkpoint, quantize_layer_weights,
+                                    save_weight_checkpoint)
+from deepcompressor_amd.data.cache import IOTensorsCache, TensorCache, TensorsCache
+from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
+from deepcompressor_amd.quantizer import QuantGptqConfig
+
+pytestmark = pytest.mark.gpu
+LS = load_golden("llm_stage")
+
+
+def build_layer(tag):
+    entries = []
+    for mod in LS.meta[tag]["modules"]:
+        r, c = mod["shape"]
+        lin = nn.Linear(c, r, bias=False).to(torch.float16).cuda()
+        lin.weight = nn.Parameter(to_device(LS[f"{tag}|{mod['name']}|w"], "f16"), requires_grad=False)
+        entries.append(LinearEntry(key=mod["key"], name=mod["name"], module=lin))
+    return entries
+
+
+@pytest.mark.parametrize("tag", sorted(LS.meta))
+def test_weight_stage_matches_reference(tag, tmp_path):
+    m = LS.meta[tag]
+    config = stage_config(m["case"])
+    entries = build_layer(tag)
+    quantizer_state_dict = {}
+    scale_sd = quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache=None,
+                                      return_with_scale_state_dict=True)
+    want_keys = sorted(k for mod in m["modules"] for k in mod["sd_keys"])
+    assert sorted(scale_sd) == want_keys
+    for k in want_keys:
+        got = scale_sd[k]
+        assert isinstance(got, torch.Tensor) and got.device.type == "cpu"
+        assert_bit_equal(to_np(got).reshape(-1), LS[f"{tag}|sd|{k}"].reshape(-1), k)
+    for e, mod in zip(entries, m["modules"]):
+        assert_bit_equal(to_np(e.module.weight.data), LS[f"{tag}|{mod['name']}|dequant"], f"{mod['name']} dequant")
+        state = quantizer_state_dict[mod["name"]]
+        assert sorted(state) == mod["state_keys"]
+        assert (state["dynamic_range"] is None) == mod["range_is_none"]
+        dyn = state["dynamic_range"]
+        dyn = (dyn,) if isinstance(dyn, dict) else (dyn or ())
+        assert len(dyn) == mod["num_ranges"]
+        for step, d in enumerate(dyn):
+            for part in ("min", "max"):
+                key = f"{tag}|{mod['name']}|range{step}|{part}"
+                if key in LS:
+                    assert d[part].device.type == "cpu"
+                    assert_bit_equal(to_np(d[part]), LS[key], key)
+    # files: write, read back with the tensor-only loader, and re-run the stage from wgts.pt alone
+    model_sd = {f"{e.name}.weight": e.module.weight.data.cpu() for e in entries}
+    written = save_weight_checkpoint(str(tmp_path), quantizer_state_dict=quantizer_state_dict,
+                                     scale_state_dict=scale_sd, model_state_dict=model_sd)
+    assert sorted(written) == ["model.pt", "scale.pt", "wgts.pt"]
+    loaded = load_weight_checkpoint(str(tmp_path))
+    assert sorted(loaded["scale.pt"]) == want_keys
+    fresh = build_layer(tag)
+    again = quantize_layer_weights(fresh, config, loaded["wgts.pt"], return_with_scale_state_dict=True)
+    for k in want_keys:
+        assert torch.equal(again[k], scale_sd[k])
+    for e, f in zip(entries, fresh):
+        assert torch.equal(e.module.weight.data, f.module.weight.data)
+
+
+def qserve_codes(weight, scale, zero, subscale, zero_pre_scaled):
+    """The integer codes the reference's QServe converter derives from model.pt + scale.pt
+    (backend/qserve/utils.py:64-179, without the final packing); its own range assertions included."""
+    w = weight.astype(np.float32)
+    oc, ic = w.shape
+    scale = np.broadcast_to(scale.reshape(-1), (oc,)).reshape(oc, 1).astype(np.float32)
+    if subscale is not None:
+        subscale = np.rint(subscale.astype(np.float32).reshape(oc, -1, 1))
+        ng = subscale.shape[1]
+        zero = np.rint(np.broadcast_to(zero.reshape(-1) if zero.size == 1 else zero.reshape(oc, ng), (oc, ng))
+                       .reshape(oc, ng, 1).astype(np.float32))
+        w = np.rint(w / scale)
+        assert w.min() >= -128 and w.max() <= 127
+        w = w.reshape(oc, ng, ic // ng)
+        if not zero_pre_scaled:
+            w = w + zero
+        w = w / subscale
+        if zero_pre_scaled:
+            zero = zero + 8 if zero.min() < 0 else zero
+            assert zero.min() >= 0 and zero.max() <= 15
+            w = w + zero
+        elif w.min() < 0:
+            w = w + 8
+        assert subscale.min() >= 0 and subscale.max() <= 127
+        assert w.min() >= 0 and w.max() <= 15
+        return w.reshape(oc, ic)
+    zero = np.broadcast_to(zero.reshape(-1), (oc,)).reshape(oc, 1).astype(np.float32)
+    if not zero_pre_scaled:
+        w = w + zero
+    w = np.rint(w / scale)
+    if zero_pre_scaled:
+        zero = np.rint(zero)
+        zero = zero + 8 if zero.min() < 0 else zero
+        assert zero.min() >= 0 and zero.max() <= 15
+        w = w + zero
+    elif w.min() < 0:
+        w = w + 8
+    assert w.min() >= 0 and w.max() <= 15
+    return w
+
+
+@pytest.mark.parametrize("tag", ["qoq_g128", "qoq_gchn_pre"])
+def test_qserve_converter_recovers_integer_codes(tag):
+    """QServe rebuilds the 4-bit codes from the dequantized fp16 weights and the saved scales; that only works if
+    the dequantized weights are exactly code * scale products.  Its arithmetic, applied to this stage's outputs,
+    must land on integers inside [0, 15] and dequantize back to the saved weights."""
+    m = LS.meta[tag]
+    config = stage_config(m["case"])
+    entries = build_layer(tag)
+    scale_sd = quantize_layer_weights(entries, config, {}, return_with_scale_state_dict=True)
+    for e in entries:
+        p = f"{e.name}.weight"
+        w = to_np(e.module.weight.data)
+        scale = to_np(scale_sd[f"{p}.scale.0"])
+        subscale = to_np(scale_sd[f"{p}.scale.1"]) if f"{p}.scale.1" in scale_sd else None
+        pre = f"{p}.zero" in scale_sd
+        zero = to_np(scale_sd[f"{p}.zero" if pre else f"{p}.scaled_zero"])
+        codes = qserve_codes(w, scale, zero, subscale, zero_pre_scaled=pre)
+        assert np.array_equal(codes, np.rint(codes))
+        assert 3 < len(np.unique(codes)) <= 16
+
+
+def test_weight_stage_with_gptq_kernel():
+    """The configured GPTQ kernel takes the linear's cached inputs (weight.py:87-92) and beats round-to-nearest on
+    the layer output."""
+    tag = "gptq_r_rtn"
+    m = LS.meta[tag]
+    g = torch.Generator().manual_seed(7)
+    entries, rtn_entries = build_layer(tag), build_layer(tag)
+    cache = {}
+    for e in entries:
+        c = e.module.in_features
+        x = (torch.randn(4, 256, c, generator=g) * torch.exp(0.7 * torch.randn(c, generator=g))).to(torch.float16).cuda()
+        cache[e.name] = IOTensorsCache(inputs=TensorsCache(TensorCache(
+            [x], channels_dim=-1, reshape=LinearReshapeFn(), num_cached=1, num_total=1, num_samples=1024,
+            orig_device=x.device)))
+    originals = [e.module.weight.data.clone() for e in entries]
+    sd = quantize_layer_weights(entries, stage_config(m["case"], kernel_gptq=QuantGptqConfig()), {}, layer_cache=cache,
+                                return_with_scale_state_dict=True)
+    quantize_layer_weights(rtn_entries, stage_config(m["case"]), {}, layer_cache=cache)
+    assert sorted(sd) == sorted(k for mod in m["modules"] for k in mod["sd_keys"])
+    for e, r, w0 in zip(entries, rtn_entries, originals):
+        x = cache[e.name].inputs.front().data[0].view(-1, w0.shape[1]).double()
+        err_gptq = (x @ (e.module.weight.data.double() - w0.double()).T).square().sum()
+        err_rtn = (x @ (r.module.weight.data.double() - w0.double()).T).square().sum()
+        assert err_gptq < err_rtn, (e.name, float(err_gptq), float(err_rtn))

@@ -124,3 +124,17 @@ def test_product_has_no_cpu_path():
     q = Quantizer(QuantizerConfig(dtype=QDType.sint4, group_shapes=((1, 128),), scale_dtypes=(torch.float16,)))
     with pytest.raises(Exception, match="GPU"):
         q.quantize(torch.zeros(2, 128, dtype=torch.float16))
+
+
+def test_llm_stage_config_names_match_reference():
+    """Cache directory names of the weight-stage config (app/llm/quant/quantizer/config.py:78-98 and the quantizer
+    config's generate_dirnames) as the reference produced them."""
+    from _stage import stage_config
+    from conftest import load_golden
+
+    LS = load_golden("llm_stage")
+    for tag, m in LS.meta.items():
+        cfg = stage_config(m["case"])
+        assert cfg.static is True
+        assert cfg.generate_calib_dirname() == m["calib_dirname"], tag
+        assert cfg.generate_dirnames(prefix="w") == m["dirnames"], tag
