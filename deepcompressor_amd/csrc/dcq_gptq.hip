@@ -16,6 +16,8 @@
 // every lane updates its remaining columns.
 #include "dcq_common.cuh"
 
+#include <type_traits>
+
 namespace dcq {
 
 // =============================================================================================
@@ -64,7 +66,9 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* __re
 }
 
 // =============================================================================================
-// SYRK on MFMA: tile 256 x 256, K step 64, 8 waves (2 x 4 grid of 128 x 64 sub-tiles), 32x32x16 instructions.
+// SYRK on MFMA: tile 256 x 256, K step 64, 8 waves (2 x 4 grid of 128 x 64 sub-tiles), 16x16x32 instructions (the
+// chip holds a higher clock on them than on the 32x32x16 form: +5 % measured here), fragment reads issued one
+// group of 4 instructions ahead of their use (+5 % more).
 // A 256-tile needs 128 flop per operand byte fetched from L2, twice what a 128-tile does: at the matrix-core peak
 // the chip-wide L2 -> LDS stream of 128-tiles would be ~39 TB/s, about twice what the L2s deliver.
 //
@@ -83,20 +87,28 @@ constexpr int kBK = 64;
 constexpr int kRowBytes = kBK * 2;                // 128 B per tile row
 constexpr int kOperandBytes = kTile * kRowBytes;  // 32 KiB
 constexpr int kSyrkThreads = 512;
-constexpr int kSyrkMT = 4, kSyrkNT = 2;           // 32 x 32 tiles per wave: 128 rows x 64 columns
 constexpr int kPatch = 8;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 template <int ST>
-__device__ __forceinline__ f32x16 mfma_32x32x16(const uint4& a, const uint4& b, f32x16 c) {
+__device__ __forceinline__ f32x4 mfma_16x16x32(const uint4& a, const uint4& b, f32x4 c) {
   if constexpr (ST == DCQ_BF16) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
                                                    0, 0);
   } else {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
                                                   0);
   }
 }
@@ -209,53 +221,59 @@ __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams 
     }                                                                                           \
   } while (0)
 
-  f32x16 acc[kSyrkMT][kSyrkNT];
+  constexpr int MT = 8, NT = 4;  // 16 x 16 tiles per wave: 128 rows x 64 columns
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int m = 0; m < kSyrkMT; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < kSyrkNT; ++n)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+      for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.0f;
 
   if (nk > 0) DCQ_STAGE(0, 0);
   wait_direct_loads();
   __syncthreads();
-  // fragment addressing: lane -> tile row (lane & 31), k-chunk (2 ks + (lane >> 5)), swizzled position
-  const int frag_row = lane & 31, frag_half = lane >> 5;
-  int a_off[kSyrkMT], a_sw[kSyrkMT], b_off[kSyrkNT], b_sw[kSyrkNT];
-#pragma unroll
-  for (int m = 0; m < kSyrkMT; ++m) {
-    const int ra = wr * 128 + m * 32 + frag_row;
-    a_off[m] = ra * kRowBytes;
-    a_sw[m] = (ra >> 1) & 7;
-  }
-#pragma unroll
-  for (int n = 0; n < kSyrkNT; ++n) {
-    const int rb = wc * 64 + n * 32 + frag_row;
-    b_off[n] = rb * kRowBytes;
-    b_sw[n] = (rb >> 1) & 7;
-  }
+  // fragment addressing (16x16x32): lane -> tile row (lane & 15), k-chunk (4 ks + (lane >> 4)), swizzled position.
+  // Every 16-row block starts at a multiple of 16, so the swizzle term (row >> 1) & 7 is the same for all blocks.
+  const int frag_row = lane & 15, frag_quarter = lane >> 4;
+  const int sw = (frag_row >> 1) & 7;
+  const int a_base = (wr * 128 + frag_row) * kRowBytes, b_base = (wc * 64 + frag_row) * kRowBytes;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) DCQ_STAGE(buf ^ 1, kt + 1);
     const unsigned char* a_lds = lds + buf * 2 * kOperandBytes;
     const unsigned char* b_lds = diag ? a_lds : a_lds + kOperandBytes;
     if (computes) {
+      // Software pipeline over the 16 (k-half, row-block) groups of this k-tile: the fragment of group g + 1 is
+      // requested before the 4 matrix instructions of group g are issued, so its LDS latency passes behind them
+      // (the scheduler is pinned to that order: left alone it pairs every read with an immediate wait).
+      const int pos0 = ((0 * 4 + frag_quarter) ^ sw) << 4, pos1 = ((1 * 4 + frag_quarter) ^ sw) << 4;
+      constexpr int D = 1;  // groups of read-ahead (2 measured no faster)
+      uint4 af[D + 1], bf[2][NT];
 #pragma unroll
-      for (int ks = 0; ks < kBK / 16; ++ks) {
-        const int chunk = ks * 2 + frag_half;
-        uint4 af[kSyrkMT], bf[kSyrkNT];
+      for (int n = 0; n < NT; ++n) bf[0][n] = *reinterpret_cast<const uint4*>(b_lds + b_base + n * 16 * kRowBytes + pos0);
 #pragma unroll
-        for (int m = 0; m < kSyrkMT; ++m)
-          af[m] = *reinterpret_cast<const uint4*>(a_lds + a_off[m] + ((chunk ^ a_sw[m]) << 4));
+      for (int d = 0; d < D; ++d) af[d] = *reinterpret_cast<const uint4*>(a_lds + a_base + d * 16 * kRowBytes + pos0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NT + D, 0);
+      static_for<2 * MT>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        constexpr int ks = g / MT, m = g % MT;
+        if constexpr (g + D < 2 * MT) {
+          constexpr int ks1 = (g + D) / MT, m1 = (g + D) % MT;
+          af[(g + D) % (D + 1)] =
+              *reinterpret_cast<const uint4*>(a_lds + a_base + m1 * 16 * kRowBytes + (ks1 ? pos1 : pos0));
+          if constexpr (m1 == 0) {
 #pragma unroll
-        for (int n = 0; n < kSyrkNT; ++n)
-          bf[n] = *reinterpret_cast<const uint4*>(b_lds + b_off[n] + ((chunk ^ b_sw[n]) << 4));
+            for (int n = 0; n < NT; ++n)
+              bf[1][n] = *reinterpret_cast<const uint4*>(b_lds + b_base + n * 16 * kRowBytes + pos1);
+          }
+        }
 #pragma unroll
-        for (int m = 0; m < kSyrkMT; ++m)
-#pragma unroll
-          for (int n = 0; n < kSyrkNT; ++n) acc[m][n] = mfma_32x32x16<ST>(af[m], bf[n], acc[m][n]);
-      }
+        for (int n = 0; n < NT; ++n) acc[m][n] = mfma_16x16x32<ST>(af[g % (D + 1)], bf[ks][n], acc[m][n]);
+        constexpr int reads = (g + D < 2 * MT) ? ((g + D) % MT == 0 ? 1 + NT : 1) : 0;
+        if constexpr (reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+      });
     }
     wait_direct_loads();  // tile kt + 1 has landed (this wave's pieces) ...
     __syncthreads();      // ... and everyone's; also fences the reads of tile kt
@@ -263,30 +281,30 @@ __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams 
 #undef DCQ_STAGE
   if (!computes) return;
 
-  // epilogue.  C/D layout of the 32x32 instruction: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const int col_in = lane & 31, row_off = 4 * (lane >> 5);
+  // epilogue.  C/D layout of the 16x16 instruction: col = lane & 15, row = reg + 4 * (lane >> 4)
+  const int col_in = lane & 15, row_off = 4 * (lane >> 4);
   if (p.splits > 1) {
     float* slab = p.partial + (static_cast<int64_t>(split) * p.num_tiles + tile_idx) * (kTile * kTile);
 #pragma unroll
-    for (int m = 0; m < kSyrkMT; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < kSyrkNT; ++n)
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wr * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + row_off;
-          const int col = wc * 64 + n * 32 + col_in;
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr * 128 + m * 16 + r + row_off;
+          const int col = wc * 64 + n * 16 + col_in;
           slab[row * kTile + col] = acc[m][n][r];
         }
     return;
   }
 #pragma unroll
-  for (int m = 0; m < kSyrkMT; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < kSyrkNT; ++n)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = bi * kTile + wr * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + row_off;
-        const int col = bj * kTile + wc * 64 + n * 32 + col_in;
+      for (int r = 0; r < 4; ++r) {
+        const int row = bi * kTile + wr * 128 + m * 16 + r + row_off;
+        const int col = bj * kTile + wc * 64 + n * 16 + col_in;
         if (row < p.C && col < p.C) {
           const float v = p.alpha * acc[m][n][r];
           if (!diag || col >= row) {
