@@ -93,3 +93,29 @@ def test_calibration_fixture():
     calib2.calibrate(x_wgts=[lin.weight], x_mods=[lin], eval_inputs=cache, eval_module=lin, eval_kwargs={})
     h = calib2.error_history
     assert len(h) < 50 and h[-1] > min(h[:-1]) and all(h[i + 1] <= h[i] for i in range(len(h) - 2))
+
+
+@pytest.mark.parametrize("shape", [(3072, 3072), (1536, 4608), (4608, 1536)])
+def test_leading_triplets_match_full_svd_at_model_size(shape):
+    """FLUX-sized weights (hidden 3072; narrower wide / tall cases for the other Gram side): the rank-32 factors from
+    the Gram route reproduce the float64 SVD's best rank-32 approximation (Eckart-Young: the residual's Frobenius norm
+    equals the tail of the spectrum) and are orthonormal / ordered as an SVD's are."""
+    from deepcompressor_amd.nn.patch.lowrank import LowRankBranch, leading_singular_triplets
+
+    g = torch.Generator().manual_seed(shape[0] + shape[1])
+    out_f, in_f = shape
+    low = torch.randn(out_f, 24, generator=g) @ torch.randn(24, in_f, generator=g) * 0.02
+    w = (low + torch.randn(out_f, in_f, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    us, vh = leading_singular_triplets(w, 32)
+    assert us.dtype == torch.float64 and us.shape == (out_f, 32) and vh.shape == (32, in_f)
+    eye = vh @ vh.T
+    assert (eye - torch.eye(32, device="cuda", dtype=torch.float64)).abs().max() < 1e-9
+    sigma = us.norm(dim=0)
+    assert (sigma[:-1] >= sigma[1:]).all()
+    s_full = torch.linalg.svdvals(w.double())
+    torch.testing.assert_close(sigma, s_full[:32], rtol=1e-9, atol=0)
+    resid = (w.double() - us @ vh).norm()
+    torch.testing.assert_close(resid, s_full[32:].norm(), rtol=1e-9, atol=0)
+    branch = LowRankBranch(in_f, out_f, 32, weight=w)
+    eff = branch.get_effective_weight()
+    assert eff.dtype == w.dtype and (eff.double() - us @ vh).abs().max() < 2e-2 * float(sigma[0]) / 32
