@@ -64,7 +64,8 @@ _SIGNATURES = {
     "dcq_selftest_division": [_p, _p, _p, _p, _p, _i64, _p],
     "dcq_scale_join": [_p, _p, _i64, _i64, _i32, _p, _p],
     "dcq_zero_point": [C.POINTER(Step), _i64, _p, _p, _p, _p],
-    "dcq_quantize_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _p, _p, _f, _f, _i32, _f, _f, _p, _i32, _p, _p],
+    "dcq_quantize_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _p, _p, _f, _f, _i32, _f, _f, _p, _i32, _p, _p,
+                            _p],
     "dcq_prescale_groups": [_p, _i32, _i64, _i64, _p, _f, _f, _p, _p],
     "dcq_dequantize_groups": [C.POINTER(Step), _p, _i64, _i64, _p, _p, _p, _i32, _f, _f, _p, _i32, _p],
     "dcq_pow_table": [_i32, _d, _p, _p],

@@ -50,6 +50,7 @@ struct GroupParams {
   // given scale/zero (quant-only / dequant-only)
   const float* scale_in;
   const float* zero_in;
+  const float* round_delta;  // [G][S]: codes = clamp(floor(t) + delta) instead of round-to-nearest, or NULL
   // previous progressive step
   const float* outer;
   float outer_lo, outer_hi;
@@ -172,7 +173,8 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
         ch = load_chunk<in_t, VEC>(xg + off);
       }
       Chunk<out_t, VEC> dq;
-      Chunk<float, VEC> qc;
+      Chunk<float, VEC> qc, delta;
+      if (want_q && p.round_delta) delta = load_chunk<float, VEC>(p.round_delta + g * p.S + off);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         float q;
@@ -180,8 +182,12 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
           float v = In::load(ch.v[i]);
           if (p.outer) v = fminf(fmaxf(v / outer, p.outer_lo), p.outer_hi);
           const float t = to_code_input<ZD>(v, s, z);
-          q = (st.tensor.kind == DCQ_ROUND_INT) ? round_int(t, st.tensor.lo, st.tensor.hi)
-                                                 : apply_rounding(st.tensor, t, cbs.v[0]);
+          if (p.round_delta) {  // integer types only (checked on the host): simple.py:47-51
+            q = fminf(fmaxf(floorf(t) + delta.v[i], st.tensor.lo), st.tensor.hi);
+          } else {
+            q = (st.tensor.kind == DCQ_ROUND_INT) ? round_int(t, st.tensor.lo, st.tensor.hi)
+                                                   : apply_rounding(st.tensor, t, cbs.v[0]);
+          }
         } else {
           q = ch.v[i];
         }
@@ -644,7 +650,7 @@ int dcq_zero_point(const dcq_step* step, int64_t n, const float* vmin, const flo
 int dcq_quantize_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S, const float* scale,
                         const float* zero, const float* outer, float outer_lo, float outer_hi, int32_t deq_clamp,
                         float deq_lo, float deq_hi, void* dequant, int32_t out_storage, float* codes,
-                        dcq_stream_t stream) {
+                        const float* round_delta, dcq_stream_t stream) {
   int rc = validate_step(step);
   if (rc != DCQ_OK) return rc;
   DCQ_REQUIRE(G >= 0 && S >= 0, DCQ_ERR_ARGUMENT, "negative size");
@@ -666,6 +672,10 @@ int dcq_quantize_groups(const dcq_step* step, const void* x, int32_t storage, in
   p.deq_hi = deq_hi;
   p.dequant = dequant;
   p.codes = codes;
+  DCQ_REQUIRE(round_delta == nullptr || step->tensor.kind == DCQ_ROUND_INT, DCQ_ERR_UNSUPPORTED,
+              "round_delta is defined for integer types only");
+  DCQ_REQUIRE((reinterpret_cast<uintptr_t>(round_delta) & 15u) == 0, DCQ_ERR_ARGUMENT, "round_delta must be 16-byte aligned");
+  p.round_delta = round_delta;
   return dispatch_storage<kQuantOnly>(p, storage, dequant ? out_storage : storage, static_cast<hipStream_t>(stream));
 }
 

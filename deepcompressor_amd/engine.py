@@ -205,15 +205,20 @@ def zero_point(step: Step, vmin: torch.Tensor, scale: torch.Tensor) -> torch.Ten
 
 
 def quantize_groups(step: Step, x: torch.Tensor, scale, zero, *, outer=None, outer_lo=0.0, outer_hi=0.0,
-                    deq_clamp=False, deq_lo=0.0, deq_hi=0.0, out_dtype=None, want_dequant=True, want_codes=False):
+                    deq_clamp=False, deq_lo=0.0, deq_hi=0.0, out_dtype=None, want_dequant=True, want_codes=False,
+                    round_delta=None):
+    """``round_delta``: float32 [G][S] (canonical group order), codes = clamp(floor(t) + delta)."""
     _require_gpu(x)
     G, S = x.shape
+    if round_delta is not None:
+        assert round_delta.shape == (G, S) and round_delta.dtype == torch.float32 and round_delta.is_contiguous()
     out_dtype = out_dtype or x.dtype
     dq = torch.empty((G, S), dtype=out_dtype, device=x.device) if want_dequant else None
     codes = torch.empty((G, S), dtype=torch.float32, device=x.device) if want_codes else None
     check(lib().dcq_quantize_groups(C.byref(step), ptr(x), storage_of(x.dtype), G, S, ptr(scale), ptr(zero), ptr(outer),
                                     outer_lo, outer_hi, int(deq_clamp), deq_lo, deq_hi, ptr(dq),
-                                    storage_of(out_dtype), ptr(codes), stream_of(x.device)), "dcq_quantize_groups")
+                                    storage_of(out_dtype), ptr(codes), ptr(round_delta), stream_of(x.device)),
+          "dcq_quantize_groups")
     return dq, codes
 
 

@@ -103,11 +103,10 @@ class QuantizerImpl:
         if isinstance(kernel, BaseQuantKernelConfig):
             kernel = kernel.build()
         native_rtn = kernel is None or type(kernel) is QuantRtnKernel
-        if native_rtn and round_delta is not None:
-            raise NotImplementedError("round_delta (learned rounding) is not implemented by the HIP kernels")
         last = self.info.steps[-1]
         dr_last = dynamic_range[-1]
-        fusable = (n_steps == 1 and native_rtn and scale[0] is None and last.scale.is_single_level()
+        fusable = (n_steps == 1 and native_rtn and round_delta is None and scale[0] is None
+                   and last.scale.is_single_level()
                    and not (dr_last is not None and dr_last.ratio is not None
                             and (dr_last.max is not None or isinstance(dr_last.ratio, torch.Tensor))))
         if fusable:
@@ -184,9 +183,14 @@ class QuantizerImpl:
         both = want_dequant and want_quant
         dq = codes = None
         if native_rtn:
+            delta = None
+            if round_delta is not None:  # impl/base.py:240-247: one delta row may serve every row group
+                assert not last.quant_dtype.is_float_point, "round_delta is not supported for float quantization"
+                rd = round_delta.view(1, 1, *view[2:]) if round_delta.shape[0] == 1 else round_delta.view(view)
+                delta, _ = engine.canonical_groups(rd.to(torch.float32).expand(view).contiguous(), view)
             dq, codes = engine.quantize_groups(step, x2d, s, z, outer=outer, outer_lo=lo, outer_hi=hi, deq_clamp=clamp,
                                                deq_lo=deq_lo, deq_hi=deq_hi, out_dtype=dtype,
-                                               want_dequant=want_dequant, want_codes=want_quant)
+                                               want_dequant=want_dequant, want_codes=want_quant, round_delta=delta)
         else:
             # caller-supplied kernel object: it receives the float32 working tensor of the last step
             if outer is not None:

@@ -16,9 +16,8 @@ __all__ = ["QuantRtnKernel", "rtn_quantize"]
 def rtn_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: QuantDataType,
                  zero_domain: ZeroPointDomain | None, scale: torch.Tensor, zero: torch.Tensor,
                  quant_range: QuantRange | None = None, round_delta: torch.Tensor | None = None) -> torch.Tensor:
-    """codes = clamp(round((x [+ z]) / s [+ z])) for a float32 working tensor; returns shape ``view_shape``."""
-    if round_delta is not None:
-        raise NotImplementedError("round_delta (learned rounding) is not implemented by the HIP kernels")
+    """codes = clamp(round((x [+ z]) / s [+ z])) for a float32 working tensor; returns shape ``view_shape``.
+    With ``round_delta`` (shaped like the view, or broadcastable to it): clamp(floor(.) + round_delta)."""
     view_shape = torch.Size(tensor.view(view_shape).shape)
     x2d, restore = engine.canonical_groups(tensor, view_shape)
     G = x2d.shape[0]
@@ -31,7 +30,12 @@ def rtn_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: Q
     if zero_domain is not None:
         z = torch.as_tensor(zero, dtype=torch.float32, device=tensor.device)
         z = z.expand([v if i % 2 == 0 else 1 for i, v in enumerate(view_shape)]).reshape(G).contiguous()
-    _, codes = engine.quantize_groups(step, x2d, s.contiguous(), z, want_dequant=False, want_codes=True)
+    delta = None
+    if round_delta is not None:
+        assert not quant_dtype.is_float_point, "round_delta is not supported for float quantization"
+        delta, _ = engine.canonical_groups(round_delta.to(torch.float32).expand(view_shape).contiguous(), view_shape)
+    _, codes = engine.quantize_groups(step, x2d, s.contiguous(), z, want_dequant=False, want_codes=True,
+                                      round_delta=delta)
     return restore(codes).view(view_shape)
 
 

@@ -147,11 +147,13 @@ int dcq_zero_point(const dcq_step* step, int64_t n, const float* vmin, const flo
 /* rtn_quantize (quantizer/kernel/rtn.py:103-117) + dequantization (quantizer/impl/base.py:262-279) of
  * x[G][S] with given per-group scale / zero.  `outer` as in dcq_group_range; with it the dequantized
  * value is clamped to [deq_lo, deq_hi] when deq_clamp (needs_dequant_saturation) and multiplied back.
- * x may be float32 working data (storage DCQ_F32) while dequant is written as `out_storage`. */
+ * x may be float32 working data (storage DCQ_F32) while dequant is written as `out_storage`.
+ * `round_delta` (NULL, or [G][S] float32): codes = clamp(floor(t) + delta) instead of round-to-nearest
+ * (quantizer/impl/simple.py:47-51), integer types only. */
 int dcq_quantize_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
                         const float* scale, const float* zero, const float* outer, float outer_lo, float outer_hi,
                         int32_t deq_clamp, float deq_lo, float deq_hi, void* dequant, int32_t out_storage,
-                        float* codes, dcq_stream_t stream);
+                        float* codes, const float* round_delta, dcq_stream_t stream);
 
 /* out[g][i] = clamp(x[g][i] / outer[g], lo, hi) in float32: the working tensor a progressive step hands to the next
  * one (quantizer/impl/base.py:221-224); only needed when a caller-supplied kernel object must see that tensor. */

@@ -1193,11 +1193,38 @@ def gen_llm_stage(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+def gen_round_delta(ref) -> None:
+    """Quantization with a rounding offset instead of round-to-nearest (quantizer/impl/simple.py:44-51,
+    kernel/rtn.py:103-117): codes = clamp(floor(t) + round_delta)."""
+    arrays, meta = {}, {}
+    for cname, dt in (("sint4_g128_f16s", "bf16"), ("uint4_post_g128_f16s", "f16"), ("uint4_pre_g128_f16s", "f32"),
+                      ("qoq_g128", "f16"), ("sint8_tnsr_f16s", "bf16")):
+        case = FAKE_QUANT_CASES[cname]
+        x = _mk_input(case["shape"], dt, seed=77 + len(cname))
+        g = torch.Generator().manual_seed(len(cname))
+        delta = (torch.rand(*case["shape"], generator=g) < 0.5).to(torch.float32)  # hard 0 / 1 decisions
+        soft = torch.rand(*case["shape"], generator=g)  # and a soft (fractional) offset
+        for kind, d in (("hard", delta), ("soft", soft)):
+            q = _build_quantizer(ref, case)
+            # channels_dim=1: without it the reference prepends a dimension to round_delta (impl/base.py:107-109) and
+            # then takes it for a single shared row (:230-234)
+            codes = q.quantize(x, return_with_dequant=False, return_with_quant=True, round_delta=d, channels_dim=1).qdata
+            q = _build_quantizer(ref, case)
+            deq = q.quantize(x, return_with_dequant=True, return_with_quant=False, round_delta=d, channels_dim=1).data
+            tag = f"{cname}|{dt}|{kind}"
+            arrays[f"{tag}|x"], arrays[f"{tag}|delta"] = _np(x), _np(d)
+            arrays[f"{tag}|codes"], arrays[f"{tag}|dequant"] = _np(codes), _np(deq)
+            meta[tag] = dict(case=cname, in_dtype=dt, kind=kind)
+    np.savez_compressed(os.path.join(OUT, "round_delta.npz"), **arrays)
+    with open(os.path.join(OUT, "round_delta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)

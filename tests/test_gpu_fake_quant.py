@@ -137,3 +137,20 @@ def test_division_by_group_scale_is_ieee_exact():
     assert bool(((fast - ref).abs()[tiny] <= ref.abs()[tiny] * 1e-6 + 1e-44).all())
     assert int(used.sum()) > n * 0.9
     assert torch.equal(ref.cpu(), x / s)
+
+
+RD = load_golden("round_delta")
+
+
+@pytest.mark.parametrize("tag", sorted(RD.meta))
+def test_round_delta_matches_reference(tag):
+    """codes = clamp(floor(t) + round_delta): hard (0 / 1) and fractional offsets, single-step and progressive."""
+    m = RD.meta[tag]
+    case = FQ.meta["cases"][m["case"]]
+    x = to_device(RD[f"{tag}|x"], m["in_dtype"])
+    delta = to_device(RD[f"{tag}|delta"], "f32")
+    q = build_quantizer(case)
+    codes = q.quantize(x, return_with_dequant=False, return_with_quant=True, round_delta=delta, channels_dim=1).qdata
+    assert_bit_equal(to_np(codes), RD[f"{tag}|codes"], "codes")
+    deq = q.quantize(x, return_with_dequant=True, return_with_quant=False, round_delta=delta, channels_dim=1).data
+    assert_bit_equal(to_np(deq), RD[f"{tag}|dequant"], "dequant")
