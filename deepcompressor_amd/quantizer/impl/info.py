@@ -94,8 +94,6 @@ class QuantScaleInfo:
 
     def native(self, device: torch.device) -> Step:
         """The dcq_step of this step on ``device`` (codebook tables live on the device)."""
-        if self.exponent_scale_quant_dtypes:
-            raise NotImplementedError("exponent (power-of-two) scale levels are not implemented by the HIP kernels")
         if device not in self._native:
             self._native[device] = engine.make_step(
                 quant_dtype=self.tensor_quant_dtype, zero_domain=self.tensor_zero_domain,
@@ -104,16 +102,31 @@ class QuantScaleInfo:
                 range_bound=self.tensor_range_bound, q_span=self.linear_tensor_quant_span, device=device)
         return self._native[device]
 
+    def _native_exponent(self, device: torch.device) -> Step:
+        """The same step with the exponent levels' tensor span: range / span is then the un-quantized scale the
+        power-of-two levels start from (quantizer/impl/scale.py:204-206)."""
+        key = ("exp", device)
+        if key not in self._native:
+            self._native[key] = engine.make_step(
+                quant_dtype=self.tensor_quant_dtype, zero_domain=self.tensor_zero_domain,
+                tensor_quant_range=self.tensor_quant_range, quant_range=self.user_quant_range,
+                scale_dtype=self.scale_quant_dtypes[-1], zero_dtype=self.zero_quant_dtype,
+                range_bound=self.tensor_range_bound, q_span=self.exponent_tensor_quant_span, device=device)
+        return self._native[key]
+
     # ---- scale tree on canonical arrays ----------------------------------------------------
-    def _quantize_levels(self, lin: torch.Tensor) -> QuantScale:
-        """quantize_scale: ``lin`` is the un-quantized scale, one value per group in canonical order."""
+    def _quantize_levels(self, lin: torch.Tensor, views=None, dtypes=None, spans=None) -> QuantScale:
+        """quantize_scale: ``lin`` is the un-quantized scale, one value per group in canonical order; the levels
+        default to the linear ones."""
+        views = self.linear_scale_view_shapes if views is None else views
+        dtypes = self.linear_scale_quant_dtypes if dtypes is None else dtypes
+        spans = self.linear_scale_quant_spans if spans is None else spans
         device, scale = lin.device, QuantScale()
         finest = self.scale_view_shapes[-1]
         keep = [s for s in finest[0::2]]  # (#g0, #g1, ...)
         s = lin
-        n_levels = len(self.linear_scale_quant_dtypes)
-        for level, (view, dtype, span) in enumerate(zip(self.linear_scale_view_shapes, self.linear_scale_quant_dtypes,
-                                                        self.linear_scale_quant_spans, strict=True)):
+        n_levels = len(dtypes)
+        for level, (view, dtype, span) in enumerate(zip(views, dtypes, spans, strict=True)):
             rounding = engine.make_rounding(dtype, has_zero_point=False, quant_range=None, device=device)
             last = level == n_levels - 1
             children = math.prod(view[1::2])
@@ -146,9 +159,9 @@ class QuantScaleInfo:
         ``outer`` (one value per group of this step, canonical order) and ``outer_range`` describe a previous
         progressive step: the measured data is clamp(tensor / outer, outer_range).
         """
-        if self.exponent_scale_quant_dtypes:
-            raise NotImplementedError("exponent (power-of-two) scale levels are not implemented by the HIP kernels")
         keep_view = [v if i % 2 == 0 else 1 for i, v in enumerate(self.tensor_view_shape)]
+        has_exp, has_lin = bool(self.exponent_scale_quant_dtypes), bool(self.linear_scale_quant_dtypes)
+        exp_raw = None  # range / exponent span (range-based) or the given scale: what the exponent levels quantize
         vmin = None
         if scale is None:
             assert isinstance(tensor, torch.Tensor), "View tensor must be a tensor."
@@ -170,12 +183,27 @@ class QuantScaleInfo:
                 if ratio.numel() != 1:
                     raise NotImplementedError("per-group range ratios are not implemented")
                 ratio = float(ratio)
+            if has_exp:
+                exp_raw, _ = engine.range_to_scale(self._native_exponent(tensor.device), vmax, vmin, ratio=ratio,
+                                                   static_max=fmt(dr.max),
+                                                   static_min=fmt(dr.min) if self.has_zero_point else None)
             lin, vmin = engine.range_to_scale(step, vmax, vmin, ratio=ratio, static_max=fmt(dr.max),
                                               static_min=fmt(dr.min) if self.has_zero_point else None)
         else:
             lin = scale.to(torch.float32).reshape(-1).contiguous()
             assert lin.numel() == self.num_groups, "scale must hold one value per quantization group"
-        s = self._quantize_levels(lin)
+            if has_exp:  # scale.py:189-190, 207-208
+                exp_raw = lin
+                if has_lin:
+                    lin = lin.mul(self.exponent_tensor_quant_span).div(self.linear_tensor_quant_span)
+        s = self._quantize_levels(lin) if has_lin else QuantScale()
+        if has_exp:  # scale.py:204-221: the power-of-two levels quantize what the linear levels left over
+            if s.data is not None:
+                s.data = s.data.expand(self.linear_scale_view_shapes[-1]).reshape(self.scale_view_shapes[-1])
+                exp_raw = exp_raw / s.data.reshape(-1)
+            exp_s = self._quantize_levels(exp_raw.contiguous(), self.exponent_scale_view_shapes,
+                                          self.exponent_scale_quant_dtypes, self.exponent_scale_quant_spans)
+            s = exp_s if s.data is None else s.extend(exp_s)
         if self.has_zero_point:
             device = s.data.device
             step = self.native(device)

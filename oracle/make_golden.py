@@ -1220,11 +1220,47 @@ def gen_round_delta(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+EXP_SCALE_CASES = {
+    # power-of-two (exponent-only) scale levels (quantizer/impl/scale.py:124-140, 204-221)
+    "sint4_g32_e8": dict(dtype="sint4", zero=None, groups=((1, 32),), sdt=("uexp8_all",), shape=(32, 256)),
+    "sint4_gchn_f16_g32_e4": dict(dtype="sint4", zero=None, groups=((1, -1), (1, 32)), sdt=("f16", "uexp4_all"),
+                                  shape=(32, 256)),
+    "uint4_post_gchn_f16_g32_e4": dict(dtype="uint4", zero="PostScale", groups=((1, -1), (1, 32)),
+                                       sdt=("f16", "uexp4_all"), shape=(32, 256)),
+    "sfp4_gchn_e8_g16_e4": dict(dtype="sfp4_e2m1_all", zero=None, groups=((1, -1), (1, 16)),
+                                sdt=("uexp8_all", "uexp4_all"), shape=(16, 128)),
+    "uint4_pre_g64_e8": dict(dtype="uint4", zero="PreScale", groups=((1, 64),), sdt=("uexp8_all",), shape=(16, 256)),
+}
+
+
+def gen_exp_scale(ref) -> None:
+    arrays, meta = {}, {}
+    for cname, case in EXP_SCALE_CASES.items():
+        for dt in ("bf16", "f16"):
+            x = _mk_input(case["shape"], dt, seed=500 + len(cname)) * (1.0 if "e8" in cname else 8.0)
+            x = x.to(TORCH_DT[dt])
+            q = _build_quantizer(ref, case)
+            r = q.quantize(x, return_with_dequant=False, return_with_quant=True)
+            q = _build_quantizer(ref, case)
+            deq = q.quantize(x, return_with_dequant=True, return_with_quant=False).data
+            tag = f"{cname}|{dt}"
+            arrays[f"{tag}|x"], arrays[f"{tag}|codes"], arrays[f"{tag}|dequant"] = _np(x), _np(r.qdata), _np(deq)
+            arrays[f"{tag}|scale"] = _np(r.scale.data)
+            for k, v in r.scale.state_dict("s").items():
+                arrays[f"{tag}|leaf|{k}"] = _np(v)
+            arrays[f"{tag}|zero"] = _np(r.zero)
+            meta[tag] = dict(case=cname, in_dtype=dt, codebook_via_restatement="fp" in case["dtype"])
+    np.savez_compressed(os.path.join(OUT, "exp_scale.npz"), **arrays)
+    with open(os.path.join(OUT, "exp_scale.json"), "w") as f:
+        json.dump(dict(cases={k: {kk: (list(vv) if kk == "shape" else vv) for kk, vv in v.items()}
+                              for k, v in EXP_SCALE_CASES.items()}, entries=meta), f, indent=1)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)

@@ -154,3 +154,26 @@ def test_round_delta_matches_reference(tag):
     assert_bit_equal(to_np(codes), RD[f"{tag}|codes"], "codes")
     deq = q.quantize(x, return_with_dequant=True, return_with_quant=False, round_delta=delta, channels_dim=1).data
     assert_bit_equal(to_np(deq), RD[f"{tag}|dequant"], "dequant")
+
+
+ES = load_golden("exp_scale")
+
+
+@pytest.mark.parametrize("tag", sorted(ES.meta["entries"]))
+def test_exponent_scale_levels_match_reference(tag):
+    """Power-of-two scale levels: alone, under a float16 per-channel level, with zero points, two exponent levels."""
+    m = ES.meta["entries"][tag]
+    case = ES.meta["cases"][m["case"]]
+    x = to_device(ES[f"{tag}|x"], m["in_dtype"])
+    q = build_quantizer(case)
+    r = q.quantize(x, return_with_dequant=False, return_with_quant=True)
+    assert_bit_equal(to_np(r.scale.data), ES[f"{tag}|scale"], "compound scale")
+    leaves = r.scale.state_dict("s")
+    want = sorted(k for k in ES.arrays.files if k.startswith(f"{tag}|leaf|"))
+    assert sorted(leaves) == [k.split("|leaf|")[1] for k in want]
+    for key in want:
+        assert_bit_equal(to_np(leaves[key.split("|leaf|")[1]]), ES[key], key)
+    assert_bit_equal(np.broadcast_to(to_np(r.zero), ES[f"{tag}|zero"].shape), ES[f"{tag}|zero"], "zero")
+    assert_bit_equal(to_np(r.qdata), ES[f"{tag}|codes"], "codes")
+    deq = q.quantize(x, return_with_dequant=True, return_with_quant=False).data
+    assert_bit_equal(to_np(deq), ES[f"{tag}|dequant"], "dequant")
