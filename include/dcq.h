@@ -323,6 +323,15 @@ int dcq_channel_metric(const void* x, int32_t storage, int64_t N, int64_t C, int
 int dcq_scale_channels(const void* x, int32_t storage, int64_t outer, int64_t C, int64_t inner, const float* scale,
                        int64_t scaled_channels, int32_t divide, void* y, int32_t out_storage, dcq_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Weight packers for the serving back ends that read the checkpoints.
+ *
+ * dcq_pack_qserve_w4: QServePacker.pack_weight (deepcompressor/backend/qserve/utils.py:18-46): codes[n][k]
+ * (uint8, values 0..15) -> out[n][k / 2] (int8) in the back end's fragment order, rows 16 apart sharing a byte
+ * (high nibble: the second row).  n and k must be multiples of 32.
+ * ------------------------------------------------------------------------------------------- */
+int dcq_pack_qserve_w4(const uint8_t* codes, int64_t n, int64_t k, int8_t* out, dcq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1256,11 +1256,59 @@ def gen_exp_scale(ref) -> None:
                               for k, v in EXP_SCALE_CASES.items()}, entries=meta), f, indent=1)
 
 
+@torch.no_grad()
+def gen_qserve(ref) -> None:
+    """The reference's QServe converter (backend/qserve/utils.py:10-210, convert.py:83-146) run on weight-stage
+    outputs of the reference: per-group W4 (QoQ progressive, int8 zero and PreScale int4 zero), per-channel W4, W8."""
+    from deepcompressor.backend.qserve.convert import convert_to_qserve_state_dict
+    from deepcompressor.backend.qserve.utils import QServePacker
+
+    arrays, meta = {}, {}
+    g = torch.Generator().manual_seed(2718)
+    codes = torch.randint(0, 16, (96, 160), generator=g, dtype=torch.uint8)
+    arrays["pack|codes"], arrays["pack|packed"] = codes.numpy().copy(), QServePacker().pack_weight(codes).numpy().copy()
+    plans = {
+        "w4_g128_post": (dict(dtype="uint4", zero="PostScale", groups=((1, -1), (1, 128)), sdt=("f16", "sint8"),
+                              inter=("sint8",), levels=(0,)), 4),
+        "w4_g128_pre": (dict(dtype="uint4", zero="PreScale", groups=((1, -1), (1, 128)), sdt=("f16", "sint8"),
+                             inter=("sint8",), levels=(0,)), 4),
+        "w4_gchn_post": (dict(dtype="uint4", zero="PostScale", groups=((1, -1),), sdt=("f16",)), 4),
+        "w4_gchn_pre": (dict(dtype="sint4", zero="PreScale", groups=((1, -1),), sdt=("f16",)), 4),
+        "w8_gchn": (dict(dtype="sint8", zero=None, groups=((1, -1),), sdt=("f16",)), 8),
+    }
+    for tag, (case, bits) in plans.items():
+        state, scales = {}, {}
+        for name, shape in (("layers.0.q_proj", (64, 256)), ("layers.0.down_proj", (96, 384))):
+            # plain heavy-tailed weights: every group spans zero, as the converter's range assertions expect
+            w = torch.randn(*shape, generator=g) * 0.02
+            w = torch.where(torch.rand(*shape, generator=g) < 0.005, w * 6, w).to(torch.float16)
+            q = _build_quantizer(ref, case)
+            r = q.quantize(w, return_with_dequant=True, return_with_quant=True)
+            arrays[f"{tag}|in|{name}.weight"] = _np(w)
+            state[f"{name}.weight"] = r.data
+            scales.update(r.scale.state_dict(f"{name}.weight.scale"))
+            zero_name = "scaled_zero" if case["zero"] == "PostScale" else "zero"
+            scales[f"{name}.weight.{zero_name}"] = r.zero if r.zero.ndim else r.zero.view(1)
+        state["layers.0.norm.weight"] = torch.ones(256, dtype=torch.float16)
+        out = convert_to_qserve_state_dict(state, scales, bits)
+        for k, v in state.items():
+            arrays[f"{tag}|model|{k}"] = _np(v)
+        for k, v in scales.items():
+            arrays[f"{tag}|scale|{k}"] = _np(v)
+        for k, v in out.items():
+            arrays[f"{tag}|out|{k}"] = v.numpy().copy() if v.dtype in (torch.int8, torch.uint8) else _np(v)
+        meta[tag] = dict(case={k: v for k, v in case.items()}, bits=bits,
+                         out={k: [str(v.dtype), list(v.shape)] for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, "qserve.npz"), **arrays)
+    with open(os.path.join(OUT, "qserve.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
