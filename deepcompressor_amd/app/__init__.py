@@ -2,10 +2,10 @@
 files they leave behind.  Model loading, datasets, evaluation and the CLI of the reference's ``app`` package are
 not part of this package."""
 
-from .llm import (LinearEntry, LlmActivationQuantizer, LlmActivationQuantizerConfig, LlmQuantizer, LlmQuantizerConfig,
-                  LlmWeightQuantizer, LlmWeightQuantizerConfig, load_weight_checkpoint, quantize_layer_weights,
+from .llm import (ActivationEntry, LinearEntry, LlmActivationQuantizer, LlmActivationQuantizerConfig, LlmQuantizer, LlmQuantizerConfig,
+                  LlmWeightQuantizer, LlmWeightQuantizerConfig, load_weight_checkpoint, quantize_layer_activations, quantize_layer_weights,
                   save_weight_checkpoint)
 
-__all__ = ["LinearEntry", "LlmActivationQuantizer", "LlmActivationQuantizerConfig", "LlmQuantizer", "LlmQuantizerConfig",
+__all__ = ["ActivationEntry", "quantize_layer_activations", "LinearEntry", "LlmActivationQuantizer", "LlmActivationQuantizerConfig", "LlmQuantizer", "LlmQuantizerConfig",
            "LlmWeightQuantizer", "LlmWeightQuantizerConfig", "load_weight_checkpoint", "quantize_layer_weights",
            "save_weight_checkpoint"]

@@ -33,8 +33,8 @@ from ..quantizer.processor import Quantizer
 from ..utils.config import SkipBasedConfig, configclass
 
 __all__ = ["LlmQuantizerConfig", "LlmWeightQuantizerConfig", "LlmActivationQuantizerConfig", "LlmQuantizer",
-           "LlmWeightQuantizer", "LlmActivationQuantizer", "LinearEntry", "quantize_layer_weights",
-           "save_weight_checkpoint", "load_weight_checkpoint"]
+           "LlmWeightQuantizer", "LlmActivationQuantizer", "LinearEntry", "ActivationEntry", "quantize_layer_weights",
+           "quantize_layer_activations", "save_weight_checkpoint", "load_weight_checkpoint"]
 
 
 @configclass
@@ -209,6 +209,65 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
             zero = result.zero
             scale_state_dict[f"{param_name}.{zero_name}"] = zero.to("cpu") if isinstance(zero, torch.Tensor) else zero
     return scale_state_dict
+
+
+@dataclass
+class ActivationEntry:
+    """One activation tensor of a layer to quantize: the inputs shared by ``modules`` (``TensorType.Inputs``; the
+    quantizer is hooked in front of each of them) or the outputs of ``modules`` (``TensorType.Outputs``; hooked behind
+    them).  ``name`` is the module name the activations are cached under (for shared inputs: the module whose input
+    cache is used, the reference takes v_proj / the first up projection).  ``eval_*`` as in :class:`LinearEntry`;
+    ``orig_weights``: (parameter, original tensor) pairs put in place while the outputs to match are computed."""
+
+    key: str
+    tensor_type: TensorType
+    modules: tp.Sequence[nn.Module]
+    name: str
+    eval_module: nn.Module | None = None
+    eval_name: str | None = None
+    eval_kwargs: dict[str, tp.Any] | None = None
+    orig_weights: list[tuple[nn.Parameter, torch.Tensor]] | None = None
+
+
+@torch.inference_mode()
+def quantize_layer_activations(entries: tp.Sequence[ActivationEntry], ipts_config: LlmActivationQuantizerConfig | None,
+                               opts_config: LlmActivationQuantizerConfig | None,
+                               quantizer_state_dict: dict[str, tp.Any],
+                               layer_cache: dict[str, IOTensorsCache] | None = None,
+                               develop_dtype: torch.dtype = torch.float32, register_hooks: bool = True
+                               ) -> dict[str, tuple[LlmActivationQuantizer, list]]:
+    """app/llm/quant/activation.py:129-192.  For every entry whose quantizer is enabled: calibrate its range on the
+    cached activations unless ``quantizer_state_dict`` (``acts.pt``) already has it under ``"{name}.input"`` /
+    ``"{name}.output"``, else reload it; then hook the quantizer onto the entry's modules so that later forwards see
+    fake-quantized activations.  Returns ``{cache key: (quantizer, hooks)}``."""
+    layer_cache = layer_cache or {}
+    out: dict[str, tuple[LlmActivationQuantizer, list]] = {}
+    for e in entries:
+        inputs = e.tensor_type == TensorType.Inputs
+        cache_key = f"{e.name}.input" if inputs else f"{e.name}.output"
+        config = ipts_config if inputs else opts_config
+        if config is None:
+            continue
+        quantizer = LlmActivationQuantizer(config, channels_dim=-1, develop_dtype=develop_dtype, key=e.key,
+                                           tensor_type=e.tensor_type)
+        if not quantizer.is_enabled():
+            continue
+        if cache_key not in quantizer_state_dict:
+            io = layer_cache.get(e.name, IOTensorsCache())
+            eval_name = e.eval_name or e.name
+            quantizer.calibrate_dynamic_range(
+                modules=list(e.modules), activations=io.inputs if inputs else io.outputs,
+                eval_module=e.eval_module, eval_inputs=layer_cache[eval_name].inputs if layer_cache else None,
+                eval_kwargs=e.eval_kwargs, orig_weights=e.orig_weights)
+            quantizer_state_dict[cache_key] = quantizer.state_dict()
+        else:
+            device = next((p.device for m in e.modules for p in m.parameters()), "cuda")
+            quantizer.load_state_dict(quantizer_state_dict[cache_key], device=device)
+        hooks = []
+        if register_hooks:
+            hooks = [quantizer.as_hook(is_output=not inputs).register(m) for m in e.modules]
+        out[cache_key] = (quantizer, hooks)
+    return out
 
 
 def save_weight_checkpoint(dirpath: str, *, quantizer_state_dict: dict[str, tp.Any] | None = None,

@@ -91,9 +91,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m
         const int mr = id / KP, k4 = (id % KP) * 4;
         const int m = m0 + mr;
         const float* row = p.A + static_cast<int64_t>(min(m, p.M - 1)) * p.lda + k0;
-        float4 v = load_piece<FAST>(row, k4, kGK);  // K is a multiple of the step: only alignment can be missing
-        if (m >= p.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        ra[it] = v;
+        // K is a multiple of the step: only alignment can be missing.  Rows past M are read from row M - 1 and
+        // zeroed when they are written to LDS, after the arithmetic of the current step: a select on the loaded
+        // value here would make the wave wait for the load before its matrix instructions.
+        ra[it] = load_piece<FAST>(row, k4, kGK);
       }
     }
   };
@@ -109,10 +110,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m
         *reinterpret_cast<float4*>(la + kr * LD + c4) = ra[it];
       } else {
         const int mr = id / KP, k4 = (id % KP) * 4;
-        la[(k4 + 0) * LD + mr] = ra[it].x;
-        la[(k4 + 1) * LD + mr] = ra[it].y;
-        la[(k4 + 2) * LD + mr] = ra[it].z;
-        la[(k4 + 3) * LD + mr] = ra[it].w;
+        const bool live = m0 + mr < p.M;
+        la[(k4 + 0) * LD + mr] = live ? ra[it].x : 0.0f;
+        la[(k4 + 1) * LD + mr] = live ? ra[it].y : 0.0f;
+        la[(k4 + 2) * LD + mr] = live ? ra[it].z : 0.0f;
+        la[(k4 + 3) * LD + mr] = live ? ra[it].w : 0.0f;
       }
     }
   };

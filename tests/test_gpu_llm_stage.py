@@ -158,3 +158,55 @@ def test_weight_stage_with_gptq_kernel():
         err_gptq = (x @ (e.module.weight.data.double() - w0.double()).T).square().sum()
         err_rtn = (x @ (r.module.weight.data.double() - w0.double()).T).square().sum()
         assert err_gptq < err_rtn, (e.name, float(err_gptq), float(err_rtn))
+
+
+def test_activation_stage_calibrates_reloads_and_hooks():
+    """smoothquant-static style: dynamic per-token int8 inputs (nothing to store) and static per-tensor int8 outputs
+    (the stored range is the largest magnitude in the cache); acts.pt entries reload into the same behaviour."""
+    from _toy import ToyGated
+
+    from deepcompressor_amd.app import ActivationEntry, LlmActivationQuantizerConfig, quantize_layer_activations
+    from deepcompressor_amd.calib.config import (SearchBasedCalibGranularity, SearchBasedCalibObjective,
+                                                 SearchBasedCalibStrategy, SkipBasedDynamicRangeCalibConfig)
+    from deepcompressor_amd.data.common import TensorType
+    from deepcompressor_amd.data.dtype import QuantDataType
+
+    g = torch.Generator().manual_seed(3)
+    mod = ToyGated(64, 96).half().cuda()
+    xs = [torch.randn(2, 12, 64, generator=g).half().cuda() for _ in range(3)]
+    cache_of = lambda data: TensorsCache(TensorCache(list(data), channels_dim=-1, reshape=LinearReshapeFn(),  # noqa: E731
+                                                     num_cached=3, num_total=3, num_samples=6, orig_device=xs[0].device))
+    with torch.inference_mode():
+        mids = [mod.up(x) * torch.sigmoid(mod.gate(x)) for x in xs]
+        baseline = mod(xs[0])
+    layer_cache = {"mlp": IOTensorsCache(inputs=cache_of(xs)), "mlp.up": IOTensorsCache(inputs=cache_of(xs)),
+                   "mlp.mid": IOTensorsCache(outputs=cache_of(mids))}
+    sint8 = QuantDataType.from_str("sint8")
+    ipts = LlmActivationQuantizerConfig(dtype=sint8, group_shapes=((1, -1),), scale_dtypes=(torch.float16,))
+    opts = LlmActivationQuantizerConfig(
+        dtype=sint8, group_shapes=((-1, -1),), scale_dtypes=(torch.float16,), static=True,
+        calib_range=SkipBasedDynamicRangeCalibConfig(objective=SearchBasedCalibObjective.OutputsError,
+                                                     strategy=SearchBasedCalibStrategy.Manual,
+                                                     granularity=SearchBasedCalibGranularity.Layer, degree=2))
+    entries = [ActivationEntry("up_proj", TensorType.Inputs, [mod.up, mod.gate], "mlp.up", mod, "mlp"),
+               ActivationEntry("mid", TensorType.Outputs, [mod.mid], "mlp.mid", mod, "mlp", {})]
+    acts = {}
+    hooked = quantize_layer_activations(entries, ipts, opts, acts, layer_cache)
+    assert sorted(acts) == ["mlp.mid.output", "mlp.up.input"]
+    assert acts["mlp.up.input"]["dynamic_range"] is None  # dynamic quantization: nothing calibrated
+    rng = acts["mlp.mid.output"]["dynamic_range"][0]
+    assert float(rng["max"]) == max(float(t.abs().max()) for t in mids) and rng["max"].device.type == "cpu"
+    with torch.inference_mode():
+        quantized = mod(xs[0])
+    assert not torch.equal(quantized, baseline) and (quantized - baseline).abs().max() < 0.05 * baseline.abs().max()
+    for _, hooks in hooked.values():
+        for h in hooks:
+            h.remove()
+    with torch.inference_mode():
+        assert torch.equal(mod(xs[0]), baseline)
+    again = quantize_layer_activations(entries, ipts, opts, acts, layer_cache=None)  # reload only
+    with torch.inference_mode():
+        assert torch.equal(mod(xs[0]), quantized)
+    for _, hooks in again.values():
+        for h in hooks:
+            h.remove()
