@@ -58,7 +58,7 @@ _SIGNATURES = {
     "dcq_round_to_codebook": [_p, _p, _i64, _i32, _p, _i32, _p],
     "dcq_fake_quant_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _p, _i32, _f, _p, _p, _p, _p, _p],
     "dcq_group_range": [_p, _i32, _i64, _i64, _i32, _p, _f, _f, _p, _p, _p],
-    "dcq_range_to_scale": [C.POINTER(Step), _i64, _p, _p, _i32, _f, _p, _p, _p, _p],
+    "dcq_range_to_scale": [C.POINTER(Step), _i64, _p, _p, _p, _i32, _f, _p, _p, _p, _p],
     "dcq_scale_level": [C.POINTER(Rounding), _p, _i64, _i64, _i32, _f, _p, _p],
     "dcq_round_values": [C.POINTER(Rounding), _p, _p, _i64, _p],
     "dcq_selftest_division": [_p, _p, _p, _p, _p, _i64, _p],

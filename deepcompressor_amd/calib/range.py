@@ -156,7 +156,9 @@ class DynamicRangeCalibrator:
         group_size = 1
         for s in self.view_shape[1::2]:
             group_size *= s
+        fp_with_zero = q.config.quant_dtype.is_float_point and q.config.zero_domain is not None
         fused = (self.pre_scale is None and info.num_steps == 1 and info.steps[0].scale.is_single_level()
+                 and not fp_with_zero
                  and tuple(info.steps[0].tensor_view_shape) == tuple(self.view_shape)
                  and group_size in (16, 32, 64, 128, 256, 512)  # the team sizes the fused kernel is built for
                  and not (q.range_bound is not None and q.range_bound.is_set()))

@@ -243,9 +243,13 @@ static int validate_step(const dcq_step* st) {
   }
   DCQ_REQUIRE(st->tensor.kind == DCQ_ROUND_INT || st->tensor.kind == DCQ_ROUND_CODEBOOK, DCQ_ERR_UNSUPPORTED,
               "tensor dtype must be an integer or a codebook (floating-point) type");
-  DCQ_REQUIRE(!(st->tensor.kind == DCQ_ROUND_CODEBOOK && st->zero_domain != DCQ_ZERO_NONE), DCQ_ERR_UNSUPPORTED,
-              "floating-point dtype with a zero point (mean-centred range) is not implemented");
   return DCQ_OK;
+}
+
+// A floating-point type with a zero point takes a range centred on the group mean (data/range.py:323-341), which
+// the kernels that measure the range themselves do not compute: such a step needs its range from the caller.
+static bool needs_mean_centred_range(const dcq_step* st) {
+  return st->tensor.kind == DCQ_ROUND_CODEBOOK && st->zero_domain != DCQ_ZERO_NONE;
 }
 
 template <int ST, int VEC, int ZD, int MODE, int OUT_ST>
@@ -338,7 +342,13 @@ __global__ __launch_bounds__(kBlock) void range_to_scale_kernel(const ScaleParam
     } else {
       vmax = p.a[i];
       if (zp) vmin = p.d[i];
-      if (p.flag) {
+      if (p.b) {  // floating-point type with a zero point: symmetric about the group mean (data/range.py:334-341)
+        const float vavg = p.b[i];
+        float vmag = fmaxf(vmax - vavg, vavg - vmin);
+        if (p.flag) vmag = vmag * p.value;
+        vmax = vavg + vmag;
+        vmin = vavg - vmag;
+      } else if (p.flag) {
         vmax = vmax * p.value;
         if (zp) vmin = vmin * p.value;
       }
@@ -509,6 +519,8 @@ int dcq_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, 
   if (G == 0 || S == 0) return DCQ_OK;
   DCQ_REQUIRE(x != nullptr, DCQ_ERR_ARGUMENT, "x is NULL");
   DCQ_REQUIRE(storage >= DCQ_F32 && storage <= DCQ_BF16, DCQ_ERR_ARGUMENT, "bad storage %d", storage);
+  DCQ_REQUIRE(range_max || !needs_mean_centred_range(step), DCQ_ERR_UNSUPPORTED,
+              "floating-point dtype with a zero point: the fused kernel needs the (mean-centred) range as input");
   DCQ_REQUIRE(!(range_max && step->zero_domain != DCQ_ZERO_NONE && !range_min), DCQ_ERR_ARGUMENT,
               "a static range with a zero point needs range_min");
   DCQ_REQUIRE(!(range_max && has_ratio), DCQ_ERR_UNSUPPORTED,
@@ -555,8 +567,9 @@ int dcq_group_range(const void* x, int32_t storage, int64_t G, int64_t S, int32_
   return dispatch_storage<kRangeOnly>(p, storage, storage, static_cast<hipStream_t>(stream));
 }
 
-int dcq_range_to_scale(const dcq_step* step, int64_t n, const float* vmax, float* vmin, int32_t has_ratio, float ratio,
-                       const float* static_max, const float* static_min, float* linear_scale, dcq_stream_t stream) {
+int dcq_range_to_scale(const dcq_step* step, int64_t n, const float* vmax, float* vmin, const float* vavg,
+                       int32_t has_ratio, float ratio, const float* static_max, const float* static_min,
+                       float* linear_scale, dcq_stream_t stream) {
   int rc = validate_step(step);
   if (rc != DCQ_OK) return rc;
   if (n == 0) return DCQ_OK;
@@ -564,10 +577,12 @@ int dcq_range_to_scale(const dcq_step* step, int64_t n, const float* vmax, float
   DCQ_REQUIRE(n > 0 && linear_scale && (vmax || static_max), DCQ_ERR_ARGUMENT, "bad arguments");
   DCQ_REQUIRE(!zp || vmin, DCQ_ERR_ARGUMENT, "vmin is NULL (it also receives the final range minimum)");
   DCQ_REQUIRE(!(static_max && zp && !has_ratio && !static_min), DCQ_ERR_ARGUMENT, "static range needs static_min");
+  DCQ_REQUIRE(!vavg || (zp && vmax), DCQ_ERR_ARGUMENT, "a group mean goes with a measured range and a zero point");
   ScaleParams p{};
   p.step = *step;
   p.n = n;
   p.a = vmax;
+  p.b = vavg;
   p.d = vmin;
   p.c = linear_scale;
   p.static_max = static_max;

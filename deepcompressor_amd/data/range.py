@@ -176,15 +176,24 @@ class DynamicRange:
         if self.ratio is None and self.max is not None:  # static range
             return DynamicRange(min=self._format_m_(self.min, shape=keep, dtype=first.dtype, device=first.device),
                                 max=self._format_m_(self.max, shape=keep, dtype=first.dtype, device=first.device))
-        if zero_domain is not None and is_float_point:
-            raise NotImplementedError("floating-point dtype with zero point (mean-centred range) is not implemented")
-        vmax = vmin = None
+        vmax = vmin = vavg = None
+        centred = zero_domain is not None and is_float_point
         for t in tensors:
             tmax, tmin = _group_min_max(t, with_min=zero_domain is not None)
             vmax = tmax if vmax is None else torch.maximum(vmax, tmax.to(vmax.device))
             if tmin is not None:
                 vmin = tmin if vmin is None else torch.minimum(vmin, tmin.to(vmin.device))
-        if self.ratio is not None:
+            if centred:  # the zero point sits at the mean of the data (data/range.py:323-328)
+                tavg = t.mean(dim=list(range(1, t.ndim, 2)), keepdim=True).to(vmax.device)
+                vavg = tavg if vavg is None else vavg + tavg
+        if centred:
+            if len(tensors) > 1:
+                vavg = vavg / len(tensors)
+            vmag = torch.maximum(vmax - vavg, vavg - vmin)
+            if self.ratio is not None:
+                vmag = vmag * self.ratio
+            vmax, vmin = vavg + vmag, vavg - vmag
+        elif self.ratio is not None:
             vmax = vmax * self.ratio
             if vmin is not None:
                 vmin = vmin * self.ratio

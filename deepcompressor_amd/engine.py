@@ -151,8 +151,9 @@ def group_range(x: torch.Tensor, *, with_min: bool, outer: torch.Tensor | None =
     return vmax, vmin
 
 
-def range_to_scale(step: Step, vmax, vmin, *, ratio=None, static_max=None, static_min=None):
-    """-> (linear_scale[n], vmin'[n] | None).  vmin' is the minimum the zero point must use."""
+def range_to_scale(step: Step, vmax, vmin, *, ratio=None, static_max=None, static_min=None, vavg=None):
+    """-> (linear_scale[n], vmin'[n] | None).  vmin' is the minimum the zero point must use.  ``vavg``: the group
+    means, for a floating-point type with a zero point (range symmetric about the mean)."""
     ref = vmax if vmax is not None else static_max
     n = ref.numel()
     lin = _f32(n, ref.device)
@@ -160,7 +161,7 @@ def range_to_scale(step: Step, vmax, vmin, *, ratio=None, static_max=None, stati
     vmin_io = None
     if zp:
         vmin_io = vmin.clone() if vmin is not None else _f32(n, ref.device)
-    check(lib().dcq_range_to_scale(C.byref(step), n, ptr(vmax), ptr(vmin_io), int(ratio is not None),
+    check(lib().dcq_range_to_scale(C.byref(step), n, ptr(vmax), ptr(vmin_io), ptr(vavg), int(ratio is not None),
                                    float(ratio or 0.0), ptr(static_max), ptr(static_min), ptr(lin),
                                    stream_of(ref.device)), "dcq_range_to_scale")
     return lin, vmin_io

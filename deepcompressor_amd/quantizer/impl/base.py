@@ -105,8 +105,9 @@ class QuantizerImpl:
         native_rtn = kernel is None or type(kernel) is QuantRtnKernel
         last = self.info.steps[-1]
         dr_last = dynamic_range[-1]
+        fp_with_zero = last.scale.has_zero_point and last.quant_dtype.is_float_point  # range centred on the mean
         fusable = (n_steps == 1 and native_rtn and round_delta is None and scale[0] is None
-                   and last.scale.is_single_level()
+                   and last.scale.is_single_level() and not fp_with_zero
                    and not (dr_last is not None and dr_last.ratio is not None
                             and (dr_last.max is not None or isinstance(dr_last.ratio, torch.Tensor))))
         if fusable:

@@ -166,18 +166,21 @@ class QuantScaleInfo:
         if scale is None:
             assert isinstance(tensor, torch.Tensor), "View tensor must be a tensor."
             step = self.native(tensor.device)
-            if self.has_zero_point and self.tensor_quant_dtype.is_float_point:
-                raise NotImplementedError("floating-point dtype with a zero point is not implemented")
             dr = dynamic_range or DynamicRange()
             static = dr.ratio is None and dr.max is not None
             fmt = lambda v: None if v is None else DynamicRange._format_m_(  # noqa: E731
                 v, shape=torch.Size(keep_view), dtype=torch.float32, device=tensor.device).contiguous().view(-1)
-            vmax = None
+            vmax = vavg = None
             if not static:
                 x2d, _ = engine.canonical_groups(tensor, self.tensor_view_shape)
                 lo, hi = (outer_range.min, outer_range.max) if outer is not None else (0.0, 0.0)
                 vmax, vmin = engine.group_range(x2d, with_min=self.has_zero_point, outer=outer, outer_lo=lo,
                                                 outer_hi=hi)
+                if self.has_zero_point and self.tensor_quant_dtype.is_float_point:
+                    # range symmetric about the group mean (data/range.py:323-341); the mean is a plain reduction
+                    if outer is not None:
+                        raise NotImplementedError("floating-point dtype with a zero point after a progressive step")
+                    vavg = x2d.to(torch.float32).mean(dim=1).contiguous()
             ratio = dr.ratio
             if isinstance(ratio, torch.Tensor):
                 if ratio.numel() != 1:
@@ -186,9 +189,9 @@ class QuantScaleInfo:
             if has_exp:
                 exp_raw, _ = engine.range_to_scale(self._native_exponent(tensor.device), vmax, vmin, ratio=ratio,
                                                    static_max=fmt(dr.max),
-                                                   static_min=fmt(dr.min) if self.has_zero_point else None)
+                                                   static_min=fmt(dr.min) if self.has_zero_point else None, vavg=vavg)
             lin, vmin = engine.range_to_scale(step, vmax, vmin, ratio=ratio, static_max=fmt(dr.max),
-                                              static_min=fmt(dr.min) if self.has_zero_point else None)
+                                              static_min=fmt(dr.min) if self.has_zero_point else None, vavg=vavg)
         else:
             lin = scale.to(torch.float32).reshape(-1).contiguous()
             assert lin.numel() == self.num_groups, "scale must hold one value per quantization group"

@@ -119,11 +119,12 @@ int dcq_group_range(const void* x, int32_t storage, int64_t G, int64_t S, int32_
                     dcq_stream_t stream);
 
 /* ratio, PreScale clamp, static bound, RangeBound, span / q_span -> un-quantized linear scale [n];
- * vmin is updated in place to the range minimum the zero point must use.
- * data/range.py:330-355, quantizer/impl/scale.py:173-188. */
-int dcq_range_to_scale(const dcq_step* step, int64_t n, const float* vmax, float* vmin, int32_t has_ratio,
-                       float ratio, const float* static_max, const float* static_min, float* linear_scale,
-                       dcq_stream_t stream);
+ * vmin is updated in place to the range minimum the zero point must use.  `vavg` (NULL, or the group
+ * means [n]): the range of a floating-point type with a zero point, symmetric about the mean with
+ * half-width max(vmax - vavg, vavg - vmin) * ratio.  data/range.py:323-355, quantizer/impl/scale.py:173-188. */
+int dcq_range_to_scale(const dcq_step* step, int64_t n, const float* vmax, float* vmin, const float* vavg,
+                       int32_t has_ratio, float ratio, const float* static_max, const float* static_min,
+                       float* linear_scale, dcq_stream_t stream);
 
 /* One level of quantize_scale (quantizer/impl/scale.py:46-62) on s[P][Q] (Q children per parent):
  *   reduce != 0: level[p] = Q(max_q s[p][q] / span), s[p][q] /= level[p]   (non-last level, or last level with Q > 1)

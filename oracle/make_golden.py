@@ -1304,11 +1304,43 @@ def gen_qserve(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+FP_ZERO_CASES = {
+    # floating-point types with a zero point: the range is centred on the group mean (data/range.py:323-341)
+    "sfp4_post_g32": dict(dtype="sfp4_e2m1_all", zero="PostScale", groups=((1, 32),), sdt=("f16",), shape=(32, 256)),
+    "sfp4_pre_g32": dict(dtype="sfp4_e2m1_all", zero="PreScale", groups=((1, 32),), sdt=("f16",), shape=(32, 256)),
+    "sfp8_post_gchn": dict(dtype="sfp8_e4m3_nan", zero="PostScale", groups=((1, -1),), sdt=("f16",), shape=(16, 256)),
+}
+
+
+def gen_fp_zero(ref) -> None:
+    from deepcompressor.data.range import DynamicRange
+
+    arrays, meta = {}, {}
+    for cname, case in FP_ZERO_CASES.items():
+        for dt in ("bf16", "f16"):
+            for ratio in (None, 0.8):
+                g = torch.Generator().manual_seed(900 + len(cname) + len(dt))
+                x = (torch.randn(*case["shape"], generator=g) * 0.05 + 0.03 * torch.randn(case["shape"][0], 1, generator=g)
+                     ).to(TORCH_DT[dt])  # rows with a non-zero mean, so that the centring matters
+                dyn = None if ratio is None else DynamicRange(ratio=ratio)
+                q = _build_quantizer(ref, case)
+                r = q.quantize(x, return_with_dequant=False, return_with_quant=True, dynamic_range=dyn)
+                deq = _build_quantizer(ref, case).quantize(x, dynamic_range=dyn).data
+                tag = f"{cname}|{dt}|r{ratio}"
+                arrays[f"{tag}|x"], arrays[f"{tag}|codes"], arrays[f"{tag}|dequant"] = _np(x), _np(r.qdata), _np(deq)
+                arrays[f"{tag}|scale"], arrays[f"{tag}|zero"] = _np(r.scale.data), _np(r.zero)
+                meta[tag] = dict(case=cname, in_dtype=dt, ratio=ratio, codebook_via_restatement=True)
+    np.savez_compressed(os.path.join(OUT, "fp_zero.npz"), **arrays)
+    with open(os.path.join(OUT, "fp_zero.json"), "w") as f:
+        json.dump(dict(cases={k: {kk: (list(vv) if kk == "shape" else vv) for kk, vv in v.items()}
+                              for k, v in FP_ZERO_CASES.items()}, entries=meta), f, indent=1)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
