@@ -333,6 +333,11 @@ int dcq_scale_channels(const void* x, int32_t storage, int64_t outer, int64_t C,
  * ------------------------------------------------------------------------------------------- */
 int dcq_pack_qserve_w4(const uint8_t* codes, int64_t n, int64_t k, int8_t* out, dcq_stream_t stream);
 
+/* dcq_pack_nunchaku: NunchakuWeightPacker.pack_weight (deepcompressor/backend/nunchaku/utils.py:16-62) for
+ * bits = 4 or 8: codes[n][k] (int8, one code per byte; only the low `bits` bits are kept) -> out[n][k * bits / 8]
+ * (int8) in the back end's fragment order.  n must be a multiple of 128, k of 128 (4 bits) or 64 (8 bits). */
+int dcq_pack_nunchaku(const int8_t* codes, int64_t n, int64_t k, int32_t bits, int8_t* out, dcq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

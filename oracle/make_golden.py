@@ -262,7 +262,7 @@ def gen_gptq(ref) -> None:
         kern = QuantGptqConfig(damp_percentage=0.01, block_size=128, num_inv_tries=250, hessian_block_size=512)
         qt = q.quantize(w, kernel=kern, inputs=cache, return_with_dequant=False, return_with_quant=True)
         dq = q.quantize(w, kernel=kern, inputs=cache, return_with_dequant=True, return_with_quant=False)
-        rtn = q.quantize(w, return_with_dequant=True, return_with_quant=False)
+        rtn = q.quantize(w, return_with_dequant=True, return_with_quant=True)
         tag = f"{cname}|{dt}|{R}x{C}|T{T}"
         arrays[f"{tag}|w"] = _np(w)
         arrays[f"{tag}|x"] = _np(x)
@@ -1304,6 +1304,107 @@ def gen_qserve(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+@torch.no_grad()
+def gen_nunchaku(ref) -> None:
+    """The reference's Nunchaku converter (backend/nunchaku/utils.py:16-352, convert.py:12-72): raw 4- and 8-bit
+    packs, scale / micro-scale / low-rank packs, and whole-linear conversions (int4 g64 with low-rank branch, smoothing
+    and shift; per-channel int4; fp4 with per-tensor scale and fp8 g16 micro scales; W8A8)."""
+    from deepcompressor.backend.nunchaku.convert import convert_to_nunchaku_w4x4y16_linear_state_dict
+    from deepcompressor.backend.nunchaku.utils import (NunchakuWeightPacker,
+                                                       convert_to_nunchaku_w8x8y16_linear_weight)
+
+    arrays, meta = {}, {}
+    g = torch.Generator().manual_seed(31337)
+
+    def put(key, t):
+        if t.dtype == torch.float8_e4m3fn:
+            arrays[key] = t.view(torch.uint8).numpy().copy()
+        elif t.dtype in (torch.int8, torch.uint8, torch.int32):
+            arrays[key] = t.numpy().copy()
+        else:
+            arrays[key] = _np(t)
+
+    for bits, shape in ((4, (256, 384)), (8, (128, 192))):
+        half = 1 << (bits - 1)
+        codes = torch.randint(-half, half, shape, generator=g, dtype=torch.int32)
+        arrays[f"pack{bits}|codes"] = codes.numpy().copy()
+        arrays[f"pack{bits}|packed"] = NunchakuWeightPacker(bits=bits).pack_weight(codes.clone()).numpy().copy()
+    packer = NunchakuWeightPacker(bits=4)
+    for dt in ("f16", "bf16"):
+        s = (torch.rand(256, 1, 6, 1, generator=g) + 0.01).to(TORCH_DT[dt])
+        put(f"scale|{dt}|in", s)
+        put(f"scale|{dt}|g64", packer.pack_scale(s, group_size=64))
+        put(f"scale|{dt}|chn", packer.pack_scale(s[:, :, :1].contiguous(), group_size=-1))
+        ms = (torch.rand(128, 1, 8, 1, generator=g) * 400).to(TORCH_DT[dt])
+        put(f"micro|{dt}|in", ms)
+        put(f"micro|{dt}|g16", packer.pack_scale(ms, group_size=16))
+        down, up = torch.randn(24, 200, generator=g).to(TORCH_DT[dt]), torch.randn(136, 24, generator=g).to(TORCH_DT[dt])
+        put(f"lowrank|{dt}|down", down), put(f"lowrank|{dt}|up", up)
+        pd = packer.pack_lowrank_weight(packer.pad_lowrank_weight(down, down=True), down=True)
+        pu = packer.pack_lowrank_weight(packer.pad_lowrank_weight(up, down=False), down=False)
+        put(f"lowrank|{dt}|down_packed", pd), put(f"lowrank|{dt}|up_packed", pu)
+        put(f"lowrank|{dt}|down_unpacked", packer.unpack_lowrank_weight(pd, down=True))
+        put(f"lowrank|{dt}|up_unpacked", packer.unpack_lowrank_weight(pu, down=False))
+
+    def linear(tag, *, oc, ic, dt, gs, rank=0, with_bias=False, with_smooth=False, with_shift=False, fused=False,
+               float_point=False, micro=False):
+        dtype = TORCH_DT[dt]
+        w = torch.randn(oc, ic, generator=g) * 0.02
+        w = torch.where(torch.rand(oc, ic, generator=g) < 0.01, w * 5, w).to(dtype)
+        if float_point:
+            case = dict(dtype="sfp4_e2m1_all", zero=None, groups=((-1, -1), (1, 16)), sdt=("f16", "sfp8_e4m3_nan"))
+            if dt == "bf16":
+                case["sdt"] = ("bf16", "sfp8_e4m3_nan")
+        else:
+            case = dict(dtype="sint4", zero=None, groups=((1, gs),), sdt=(dt,))
+        r = _build_quantizer(ref, case).quantize(w, return_with_dequant=True, return_with_quant=True)
+        scales = r.scale.state_dict("s")
+        kwargs = dict(weight=r.data.clone(), scale=scales["s.0"], float_point=float_point)
+        if micro:
+            kwargs["subscale"] = scales["s.1"]
+        if with_bias:
+            kwargs["bias"] = torch.randn(oc, generator=g).to(dtype)
+        if with_smooth:
+            kwargs["smooth"] = (torch.rand(ic, generator=g) + 0.5).to(dtype)
+            kwargs["smooth_fused"] = fused
+        if with_shift:
+            kwargs["shift"] = torch.randn(ic, generator=g).to(dtype) * 0.1
+        if rank:
+            kwargs["lora"] = ((torch.randn(rank, ic, generator=g) * 0.05).to(dtype),
+                              (torch.randn(oc, rank, generator=g) * 0.05).to(dtype))
+        for k, v in kwargs.items():
+            if isinstance(v, torch.Tensor):
+                put(f"{tag}|in|{k}", v)
+            elif isinstance(v, tuple):
+                put(f"{tag}|in|lora_down", v[0]), put(f"{tag}|in|lora_up", v[1])
+        out = convert_to_nunchaku_w4x4y16_linear_state_dict(**kwargs)
+        for k, v in out.items():
+            put(f"{tag}|out|{k}", v)
+        meta[tag] = dict(oc=oc, ic=ic, dtype=dt, float_point=float_point, smooth_fused=fused,
+                         out={k: [str(v.dtype), list(v.shape)] for k, v in out.items()})
+
+    linear("w4_g64_branch", oc=200, ic=320, dt="bf16", gs=64, rank=24, with_bias=True, with_smooth=True, with_shift=True)
+    linear("w4_g64_fused", oc=128, ic=256, dt="f16", gs=64, rank=16, with_smooth=True, fused=True)
+    linear("w4_g64_plain", oc=256, ic=128, dt="f16", gs=64)
+    linear("w4_chn", oc=128, ic=128, dt="bf16", gs=128)
+    linear("w4_fp4_micro", oc=136, ic=192, dt="bf16", gs=16, rank=8, float_point=True, micro=True)
+
+    for dt in ("f16", "bf16"):
+        dtype = TORCH_DT[dt]
+        w = (torch.randn(130, 200, generator=g) * 0.02).to(dtype)
+        r = _build_quantizer(ref, dict(dtype="sint8", zero=None, groups=((1, -1),), sdt=(dt,))).quantize(
+            w, return_with_dequant=True, return_with_quant=True)
+        bias = torch.randn(130, generator=g).to(dtype)
+        put(f"w8|{dt}|in|weight", r.data), put(f"w8|{dt}|in|scale", r.scale.data), put(f"w8|{dt}|in|bias", bias)
+        qw, qs, qb = convert_to_nunchaku_w8x8y16_linear_weight(r.data.clone(), r.scale.data, bias)
+        put(f"w8|{dt}|out|weight", qw), put(f"w8|{dt}|out|scale", qs), put(f"w8|{dt}|out|bias", qb)
+        meta[f"w8|{dt}"] = dict(out={"weight": [str(qw.dtype), list(qw.shape)], "scale": [str(qs.dtype), list(qs.shape)],
+                                     "bias": [str(qb.dtype), list(qb.shape)]})
+    np.savez_compressed(os.path.join(OUT, "nunchaku.npz"), **arrays)
+    with open(os.path.join(OUT, "nunchaku.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 FP_ZERO_CASES = {
     # floating-point types with a zero point: the range is centred on the group mean (data/range.py:323-341)
     "sfp4_post_g32": dict(dtype="sfp4_e2m1_all", zero="PostScale", groups=((1, 32),), sdt=("f16",), shape=(32, 256)),
@@ -1340,7 +1441,7 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
