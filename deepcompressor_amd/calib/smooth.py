@@ -2,15 +2,17 @@
 
 Same call surface as the reference: ``smooth_linear_modules`` (weight-centric, x-w) and ``smooth_attention``
 (outputs-centric, query-key) with a given scale or a ``SmoothLinearCalibrator`` / ``SmoothAttentionCalibrator``
-search (Manual / GridSearch over (alpha, beta) x span pairs, scored on the outputs of an evaluation module, Layer
-granularity).  What runs where:
+search (Manual / GridSearch over (alpha, beta) x span pairs), scored on the outputs of an evaluation module (Layer
+granularity) or on the x-w products of the linears themselves (ProductsError: Layer, or one winner per group of input
+channels).  What runs where:
 
 * per-channel spans of activations and weights        -> ``dcq_channel_metric``   (one pass each, HBM-bound)
 * ``W * s`` / ``W / s`` / ``x / s`` / ``x * s`` (+ cast) -> ``dcq_scale_channels``   (one pass, fused cast)
 * fake quantization of the scaled tensors             -> the ``Quantizer`` kernels
 * the evaluation module's forward                     -> torch on the GPU (the module belongs to the caller)
+* products of the processed x and w per channel group -> one batched GEMM, errors by ``dcq_product_error``
 
-Not implemented (raise): ProductsError / ChannelGroup scoring of smoothing candidates.
+Not implemented (raise): TensorError scoring of smoothing candidates, ProductsError on convolution weights.
 """
 
 from __future__ import annotations
@@ -23,9 +25,11 @@ from dataclasses import dataclass
 import torch
 import torch.nn as nn
 
+from .. import engine
 from .._lib import check, lib, storage_of, stream_of
 from ..data.cache import TensorsCache
 from ..data.common import TensorType
+from ..data.utils.shape import infer_view_shape
 from ..quantizer.processor import ProcessHook, Quantizer
 from .config.search import SearchBasedCalibGranularity, SearchBasedCalibObjective
 from .config.smooth import SmoothCalibConfig, SmoothSpanMode
@@ -238,15 +242,62 @@ class SmoothCalibrator:
             self.candidate = get_smooth_scale(alpha_base=a_span, beta_base=b_span, alpha=alpha, beta=beta)
         return self.candidate
 
+    @staticmethod
+    def _update_best(*, best_error: list[torch.Tensor] | None, best_scale: torch.Tensor | None,
+                     error: list[torch.Tensor], scale: torch.Tensor, numel: int, num_channels: int, num_heads: int,
+                     num_head_repeats: int) -> tuple[list[torch.Tensor], torch.Tensor]:
+        """smooth.py:655-714.  One error per candidate: it replaces the best when it is not worse on every error
+        (ties move on).  One error per group of input channels: a group takes the candidate's scale where the
+        candidate is strictly better on every error; with grouped-query heads the errors of the heads that share a
+        key/value head are added first, so those heads switch together."""
+        if best_error is None:
+            return error, scale
+        if numel == 1:
+            if all(bool(e <= b) for b, e in zip(best_error, error, strict=True)):
+                return error, scale
+            return best_error, best_scale
+        assert num_channels % numel == 0
+        group_size, num_groups = num_channels // numel, numel
+        shared = num_heads > 1 and num_head_repeats > 1
+        if shared:
+            head_channels, unique_heads = num_channels // num_heads, num_heads // num_head_repeats
+            groups_per_head, repeats, unique_per_group = 1, 1, 1
+            if head_channels >= group_size:
+                assert head_channels % group_size == 0
+                groups_per_head, repeats = head_channels // group_size, num_head_repeats
+            else:
+                assert group_size % head_channels == 0
+                heads_per_group = group_size // head_channels
+                if heads_per_group < num_head_repeats:
+                    assert num_head_repeats % heads_per_group == 0
+                    repeats = num_head_repeats // heads_per_group
+                else:
+                    assert heads_per_group % num_head_repeats == 0
+                    unique_per_group = heads_per_group // num_head_repeats
+            uniques = unique_heads // unique_per_group
+            shared = repeats > 1
+        pos = torch.full((numel,), True, device=error[0].device)
+        for b, e in zip(best_error, error, strict=True):
+            if shared:
+                b = b.view(uniques, repeats, groups_per_head).sum(dim=1, keepdim=True)
+                e = e.view(uniques, repeats, groups_per_head).sum(dim=1, keepdim=True)
+                pos = pos & (e < b).expand(uniques, repeats, groups_per_head).reshape_as(pos)
+            else:
+                pos = pos & (e < b)
+        for b, e in zip(best_error, error, strict=True):
+            b[pos] = e[pos]
+        pos = pos.view(num_groups, 1).expand(num_groups, group_size)
+        best_scale = best_scale.view(num_groups, group_size)
+        best_scale[pos] = scale.view(num_groups, group_size)[pos]
+        return best_error, best_scale
+
     def tell(self, error: list[torch.Tensor]) -> None:
         numel = error[0].numel()
         assert all(e.numel() == numel for e in error)
-        if numel != 1:
-            raise NotImplementedError("channel-group wise smoothing errors are not implemented")
-        self.error_history.append(error)
-        # Layer granularity: a candidate replaces the best when it is not worse on every error (ties move on)
-        if self.best_error is None or all(bool(e <= b) for b, e in zip(self.best_error, error, strict=True)):
-            self.best_error, self.best_scale = error, self.candidate
+        self.error_history.append([e.clone() for e in error])
+        self.best_error, self.best_scale = self._update_best(
+            best_error=self.best_error, best_scale=self.best_scale, error=error, scale=self.candidate, numel=numel,
+            num_channels=self.num_in_channels, num_heads=self.num_heads, num_head_repeats=self.num_head_repeats)
         self.candidate_id += 1
         if self.candidate_id >= self.population_size:
             self.iter += 1
@@ -364,13 +415,20 @@ class SmoothCalibrator:
         outputs_centric = self.tensor_type == TensorType.Outputs
         if outputs_centric:  # search.py:363-366
             objective, granularity = SearchBasedCalibObjective.OutputsError, SearchBasedCalibGranularity.Layer
-        if objective == SearchBasedCalibObjective.OutputsError and not (
-                not outputs_centric and isinstance(eval_module, (nn.Linear, nn.Conv2d))
-                and granularity != SearchBasedCalibGranularity.Layer):
-            granularity = SearchBasedCalibGranularity.Layer
-        else:
-            raise NotImplementedError(f"smoothing search with {objective.name} / {granularity.name} is not implemented")
+        if objective == SearchBasedCalibObjective.OutputsError:
+            assert eval_inputs is not None, "eval_inputs should not be None when objective is OutputsError"
+            assert eval_module is not None, "eval_module should not be None when OutputsError"
+            if (not outputs_centric and isinstance(eval_module, (nn.Linear, nn.Conv2d))
+                    and granularity != SearchBasedCalibGranularity.Layer):
+                objective = SearchBasedCalibObjective.ProductsError  # search.py:397-409
+            else:
+                granularity = SearchBasedCalibGranularity.Layer
         self.objective, self.granularity = objective, granularity
+        if objective == SearchBasedCalibObjective.ProductsError:
+            return self._calibrate_products(x_wgts, x_acts or eval_inputs, orig_x_wgts,
+                                            kwargs.get("orig_x_acts") or orig_eval_inputs)
+        if objective != SearchBasedCalibObjective.OutputsError:
+            raise NotImplementedError(f"smoothing search with {objective.name} is not implemented")
         assert eval_inputs is not None, "eval_inputs should not be None when objective is OutputsError"
         assert eval_module is not None, "eval_module should not be None when OutputsError"
         x_acts = x_acts or eval_inputs
@@ -410,6 +468,73 @@ class SmoothCalibrator:
                 total = y if total is None else total.add_(y)
             self._recover_mod()
             self.tell([total])
+        return self.get_best()
+
+
+    def _calibrate_products(self, x_wgts: list[nn.Parameter], x_acts: TensorsCache | None,
+                            orig_x_wgts: list[tuple[nn.Parameter, torch.Tensor]] | None,
+                            orig_x_acts: TensorsCache | None) -> torch.Tensor:
+        """ProductsError (search.py:697-745, 791-816): every candidate is scored on the products of the processed
+        input batches with the processed weights against the products of the originals, in the weights' dtype.
+        Layer granularity takes the whole product x @ w^T; ChannelGroup / Group take the partial products of each
+        quantization group of input channels (one batched GEMM over the groups here), summed per channel group or
+        kept per (row, group)."""
+        assert x_acts is not None, "x_acts should not be None when objective is ProductsError"
+        assert self.w_quantizer is not None, "ProductsError takes the group geometry from the weight quantizer"
+        wgts = [w.detach().data for w in x_wgts]
+        origs = wgts if orig_x_wgts is None else [w for _, w in orig_x_wgts]
+        assert len(origs) == len(wgts)
+        if any(w.ndim != 2 for w in wgts):
+            raise NotImplementedError("ProductsError smoothing search is implemented for 2-D (linear) weights")
+        views = [infer_view_shape(w.shape, self.w_quantizer.config.largest_group_shape) for w in wgts]
+        if any(v[1] != 1 for v in views):
+            raise NotImplementedError("ProductsError smoothing search needs (1, g) weight groups")
+        layer = self.granularity == SearchBasedCalibGranularity.Layer
+        dev, dt = wgts[0].device, wgts[0].dtype
+
+        def parse(cache: TensorsCache | None) -> TensorsCache | None:
+            if cache is None:
+                return None
+            return TensorsCache({key: ipt.repartition(max_batch_size=self.config.element_batch_size,
+                                                      max_size=self.config.element_size, standardize=True, reshape=True)
+                                 for key, ipt in cache.items()})
+
+        ipts, orig_ipts = parse(x_acts), parse(orig_x_acts)
+        self.reset(x_wgts=x_wgts, x_acts=x_acts)
+        assert ipts.num_tensors == 1, "linears that share a smoothing scale take one input"
+        cache = ipts.front()
+
+        def products(x: torch.Tensor, w: torch.Tensor, view) -> torch.Tensor:
+            """x [n, C] and w [R, C] -> [n, R] (Layer) or [CG * R, n] (partial products per channel group)."""
+            x = cache.reshape(x).view(x.shape[0], -1).to(device=dev, dtype=dt)
+            if layer:
+                return torch.matmul(x, w.view(w.shape[0], -1).t()).contiguous()
+            R, _, CG, g = view
+            xg = x.view(-1, CG, g).permute(1, 2, 0)
+            return torch.bmm(w.view(R, CG, g).transpose(0, 1), xg).view(CG * R, -1)
+
+        orig_cache = cache if orig_ipts is None else orig_ipts.front()
+        base = [[products(x, w, view) for x in orig_cache.data] for w, view in zip(origs, views)]
+        degree = float(self.config.degree)
+        while not self.is_done():
+            self.ask()
+            batches = [self._process_x_in_xw(x.to(dev), channels_dim=cache.channels_dim) for x in cache.data]
+            errors = []
+            for w, view, y0s in zip(wgts, views, base, strict=True):
+                qw = self._process_w_in_xw(w)
+                total = None
+                for x, y0 in zip(batches, y0s, strict=True):
+                    total = engine.product_error(products(x, qw, view), y0, degree, out=total)
+                if layer:
+                    total = total.double().sum().to(torch.float32).view(1)
+                else:
+                    total = total.view(view[2], view[0])
+                    if self.granularity == SearchBasedCalibGranularity.ChannelGroup:
+                        total = total.double().sum(dim=1).to(torch.float32)
+                    else:
+                        total = total.t().contiguous()
+                errors.append(total)
+            self.tell(errors)
         return self.get_best()
 
 

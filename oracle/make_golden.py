@@ -461,6 +461,78 @@ def gen_smooth(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+SMOOTH_PRODUCTS_CASES = {
+    # tag: objective, granularity, dtype, heads, repeats, quantize inputs, evaluation module is the linear itself
+    "products_chgroup": ("ProductsError", "ChannelGroup", "f32", 1, 1, True, False),
+    "products_group": ("ProductsError", "Group", "f32", 1, 1, False, False),  # the config turns Group into ChannelGroup
+    "products_chgroup_f16": ("ProductsError", "ChannelGroup", "f16", 1, 1, False, False),
+    "outputs_linear_chgroup": ("OutputsError", "ChannelGroup", "f32", 1, 1, True, True),
+    "products_chgroup_gqa": ("ProductsError", "ChannelGroup", "f32", 4, 2, True, False),
+    "products_chgroup_gqa_wide": ("ProductsError", "ChannelGroup", "f32", 8, 2, False, False),
+}
+
+
+def gen_smooth_products(ref) -> None:
+    """The reference's smoothing search scored on x-w products (calib/search.py:697-745, 791-816) with one winner per
+    group of input channels (calib/smooth.py:655-714): every candidate's error tensors and the final scale."""
+    import torch.nn as nn
+    from deepcompressor.calib import smooth as rs
+    from deepcompressor.calib.config import SearchBasedCalibGranularity, SearchBasedCalibObjective, SearchBasedCalibStrategy
+    from deepcompressor.calib.config.smooth import SmoothCalibConfig, SmoothSpanMode
+    from deepcompressor.data.cache import TensorCache, TensorsCache
+    from deepcompressor.data.dtype import QuantDataType
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+    from deepcompressor.quantizer import Quantizer as RefQuantizer
+    from deepcompressor.quantizer.config.base import QuantizerConfig as RefQuantizerConfig
+
+    arrays, meta = {}, {}
+    g = torch.Generator().manual_seed(4242)
+    for tag, (objective, granularity, dt, heads, repeats, quant_x, linear_eval) in SMOOTH_PRODUCTS_CASES.items():
+        dtype = TORCH_DT[dt]
+        rows = (40,) if linear_eval else (40, 24)
+        mods = [nn.Linear(64, r, bias=False).to(dtype) for r in rows]
+        for m in mods:
+            m.weight.data = (torch.randn(m.weight.shape, generator=g) * 0.08).to(dtype)
+        gains = torch.exp(torch.randn(64, generator=g) * 1.2)
+        xs = [(torch.randn(2, 12, 64, generator=g) * gains).to(dtype) for _ in range(3)]
+        for i, m in enumerate(mods):
+            arrays[f"{tag}|w{i}"] = _np(m.weight.data)
+        for i, x in enumerate(xs):
+            arrays[f"{tag}|x{i}"] = _np(x)
+        wq = RefQuantizer(RefQuantizerConfig(dtype=QuantDataType.from_str("sint4"), zero_point=None,
+                                             group_shapes=((1, 16),), scale_dtypes=(torch.float16,)), key="w")
+        xq = RefQuantizer(RefQuantizerConfig(dtype=QuantDataType.from_str("sint8"), zero_point=None,
+                                             group_shapes=((1, -1),), scale_dtypes=(torch.float16,)), channels_dim=-1,
+                          key="x") if quant_x else None
+        cfg = SmoothCalibConfig(spans=[(SmoothSpanMode.AbsMax, SmoothSpanMode.AbsMax)], alpha=0.5, beta=-2, num_grids=10,
+                                strategy=SearchBasedCalibStrategy.GridSearch,
+                                objective=SearchBasedCalibObjective[objective],
+                                granularity=SearchBasedCalibGranularity[granularity], degree=2)
+        cache = TensorsCache(TensorCache(list(xs), channels_dim=-1, reshape=LinearReshapeFn(), num_cached=3, num_total=3,
+                                         num_samples=6, orig_device=torch.device("cpu")))
+        calib = rs.SmoothLinearCalibrator(cfg, wq, xq, num_heads=heads, num_head_repeats=repeats)
+        errors, scales = [], []
+        orig_tell = calib._tell
+
+        def spy(error, _orig=orig_tell, _errors=errors, _scales=scales, _calib=calib):
+            _errors.append(torch.stack([e.detach().clone().float().view(-1) for e in error]))
+            _scales.append(_calib.candidate.detach().clone())
+            return _orig(error)
+
+        calib._tell = spy
+        best = calib.calibrate(x_wgts=[m.weight for m in mods], x_acts=cache, x_mods=mods, eval_inputs=cache,
+                               eval_module=mods[0] if linear_eval else None, eval_kwargs={})
+        arrays[f"{tag}|errors"] = torch.stack(errors).numpy()  # [candidates, weights, groups or 1]
+        arrays[f"{tag}|scales"] = torch.stack(scales).numpy()
+        arrays[f"{tag}|best_scale"] = best.float().numpy().copy()
+        meta[tag] = dict(objective=objective, granularity=granularity, dtype=dt, num_heads=heads, num_head_repeats=repeats,
+                         quantize_inputs=quant_x, linear_eval=linear_eval, rows=list(rows),
+                         num_candidates=len(errors))
+    np.savez_compressed(os.path.join(OUT, "smooth_products.npz"), **arrays)
+    with open(os.path.join(OUT, "smooth_products.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 @torch.no_grad()
 def gen_lowrank(ref) -> None:
     """Low-rank branches, joint quantization and the alternating calibration from the reference
@@ -1441,7 +1513,7 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)

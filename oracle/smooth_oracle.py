@@ -177,3 +177,73 @@ def candidate_error_low_rank(weights, xs, scale, w_spec, x_spec, rank: int, *, e
         y0 = np.concatenate([x.astype(F32) @ w.astype(F32).T for w in weights], axis=-1)
         total += float(np.sum(np.power((y - y0).astype(F32), degree), dtype=np.float64))
     return total
+
+
+def products_errors(weights, xs, scale, w_spec, x_spec, dt: str, group: int, degree: float = 2):
+    """ProductsError of one smoothing candidate per group of ``group`` input channels (search.py:791-816 with the
+    reshapes of search.py:26-42): for every linear, sum over rows and tokens of
+    (dt(x_g' @ w_g'^T) - dt(x_g @ w_g^T))^degree, where ' marks the processed tensors of smooth.py:504-530."""
+    s = scale.astype(F32)
+    out = []
+    x_proc = []
+    for x in xs:
+        x2 = x.reshape(-1, x.shape[-1]).astype(F32)
+        if x_spec is not None:
+            xd = (x2 / s).astype(F32)
+            xq = qo.fake_quantize(xd, "f32", x_spec, default_dtype=dt)["dequant"]
+            x_proc.append(qo.round_to(dt, (xq * s).astype(F32)))
+        else:
+            x_proc.append(x2)
+    for w in weights:
+        ws = (w.astype(F32) * s[None, :]).astype(F32)
+        wq = qo.fake_quantize(ws, "f32", w_spec, default_dtype=dt)["dequant"]
+        wp = qo.round_to(dt, (wq / s[None, :]).astype(F32))
+        rows, cols = w.shape
+        total = np.zeros(cols // group, np.float64)
+        for x, xp in zip(xs, x_proc):
+            x2 = x.reshape(-1, cols).astype(F32)
+            part = lambda a, b: qo.round_to(dt, np.einsum(  # noqa: E731
+                "ngi,rgi->rgn", a.reshape(-1, cols // group, group), b.reshape(rows, cols // group, group)).astype(F32))
+            diff = qo.round_to(dt, part(xp, wp) - part(x2, w.astype(F32)))
+            total += np.power(diff.astype(np.float64), degree).sum(axis=(0, 2))
+        out.append(total)
+    return out
+
+
+def update_best(best_error, best_scale, error, scale, num_channels: int, num_heads: int = 1, num_head_repeats: int = 1):
+    """SmoothCalibrator._update_best (smooth.py:655-714) on lists of per-group error vectors."""
+    if best_error is None:
+        return [e.copy() for e in error], scale.copy()
+    numel = error[0].size
+    if numel == 1:
+        if all(float(e) <= float(b) for b, e in zip(best_error, error)):
+            return [e.copy() for e in error], scale.copy()
+        return best_error, best_scale
+    group = num_channels // numel
+    shared = num_heads > 1 and num_head_repeats > 1
+    if shared:
+        head_channels, unique_heads = num_channels // num_heads, num_heads // num_head_repeats
+        per_head, repeats, unique_per_group = 1, 1, 1
+        if head_channels >= group:
+            per_head, repeats = head_channels // group, num_head_repeats
+        else:
+            heads_per_group = group // head_channels
+            if heads_per_group < num_head_repeats:
+                repeats = num_head_repeats // heads_per_group
+            else:
+                unique_per_group = heads_per_group // num_head_repeats
+        uniques = unique_heads // unique_per_group
+        shared = repeats > 1
+    pos = np.ones(numel, bool)
+    for b, e in zip(best_error, error):
+        if shared:
+            bs = b.reshape(uniques, repeats, per_head).sum(axis=1, keepdims=True, dtype=b.dtype)
+            es = e.reshape(uniques, repeats, per_head).sum(axis=1, keepdims=True, dtype=e.dtype)
+            pos &= np.broadcast_to(es < bs, (uniques, repeats, per_head)).reshape(-1)
+        else:
+            pos &= e < b
+    for b, e in zip(best_error, error):
+        b[pos] = e[pos]
+    best_scale = best_scale.copy().reshape(numel, group)  # the reference hands back this 2-D view (smooth.py:712-714)
+    best_scale[pos] = scale.reshape(numel, group)[pos]
+    return best_error, best_scale
