@@ -125,6 +125,7 @@ class DynamicRangeCalibrator:
             inputs = self.tensor_type == TensorType.Inputs
             self.path = "general"
             self._calibrate_acts(acts=x_acts if inputs else y_acts, mods=x_mods if inputs else y_mods,
+                                 wgts=x_wgts if inputs else None, orig_acts=orig_x_acts if inputs else orig_y_acts,
                                  eval_inputs=eval_inputs, eval_module=eval_module, eval_kwargs=eval_kwargs or {},
                                  orig_wgts=(orig_x_wgts or []) + (orig_y_wgts or []),
                                  orig_eval_inputs=orig_eval_inputs, record_errors=record_errors)
@@ -377,14 +378,15 @@ class DynamicRangeCalibrator:
 
     # ---- activations (calib/range.py:101-150, calib/search.py:839-1078) --------------------------------------
     def _calibrate_acts(self, acts, mods, eval_inputs, eval_module, eval_kwargs, orig_wgts, orig_eval_inputs,
-                        record_errors: bool) -> None:
+                        record_errors: bool, wgts=None, orig_acts=None) -> None:
         """Range of a module's inputs or outputs.  The cached batches, flattened ahead of the channel dimension, are
         viewed with the whole first dimension inside the group (``skip_first_dim``), so a static range is shared by
         all tokens.  Clamp-based search (static tensors, or ``allow_scale`` off): candidates are the measured range
         times each ratio; otherwise the candidate is the ratio itself, applied to the range the quantizer measures
         on the fly.  A candidate is scored on the tensor (inputs only: |Q(x) - x|^degree per channel group or in
         total, summed per batch in the tensor's dtype and added up in that dtype as the reference does) or on the
-        evaluation module's outputs with the quantizer hooked onto the modules."""
+        evaluation module's outputs with the quantizer hooked onto the modules, or (inputs only) on the products of
+        the quantized input with the weights of the linears that consume it."""
         what = "input" if self.tensor_type == TensorType.Inputs else "output"
         assert acts is not None, f"The {what} activations should be provided."
         assert acts.num_tensors == 1, f"Only one {what} is allowed, got {acts.num_tensors}"
@@ -403,8 +405,6 @@ class DynamicRangeCalibrator:
                 self.objective = SearchBasedCalibObjective.ProductsError
             else:
                 self.granularity = SearchBasedCalibGranularity.Layer
-        if self.objective == SearchBasedCalibObjective.ProductsError:
-            raise self._unsupported("ProductsError for activations")
         if self.pre_scale is not None:
             raise self._unsupported("progressive quantizers on activations")
         device = _device_of(cache, mods, eval_module)
@@ -420,6 +420,10 @@ class DynamicRangeCalibrator:
                 # calib/search.py:933-942: the Group branch falls through into the final else
                 raise ValueError(f"Unknown granularity {self.granularity}")
             scorer = self._acts_tensor_scorer(cache, batches, view)
+        elif self.objective == SearchBasedCalibObjective.ProductsError:
+            assert self.tensor_type == TensorType.Inputs, "ProductsError scores inputs (or weights)"
+            assert wgts, "wgts should not be None when objective is ProductsError"
+            scorer = self._acts_products_scorer(acts, wgts, orig_wgts, orig_acts or orig_eval_inputs, device)
         else:
             assert self.objective == SearchBasedCalibObjective.OutputsError
             scorer = self._acts_outputs_scorer(mods, eval_inputs, eval_module, eval_kwargs, orig_wgts, orig_eval_inputs)
@@ -461,6 +465,55 @@ class DynamicRangeCalibrator:
                 e = e.to(x.dtype)
                 total = e if total is None else total.add_(e)
             return total
+
+        return score
+
+    def _acts_products_scorer(self, acts: TensorsCache, wgts, orig_wgts, orig_acts: TensorsCache | None, device):
+        """calib/search.py:871-901, 947-973.  Every cached batch x[n, C] is multiplied with every weight w[R, C] of
+        the linears that consume it, one quantization group of input channels at a time (a batched GEMM over the
+        C/g groups; the whole product for Layer granularity), in the tensors' dtype; the candidate's error is
+        sum float32(dtype(Q(x) w - x0 w0))^degree per channel group, added up over batches and weights in float32.
+        The weights are not processed (the reference quantizes only the tensor being calibrated)."""
+        view = self.view_shape
+        if len(view) != 4:
+            raise self._unsupported("ProductsError for inputs that are not [tokens, channels]")
+        CG, g = view[2], view[3]
+        layer = self.granularity == SearchBasedCalibGranularity.Layer
+        degree = float(self.config.degree)
+
+        def parse(cache: TensorsCache | None):
+            if cache is None:
+                return None
+            return cache.front().repartition(max_batch_size=self.config.element_batch_size,
+                                             max_size=self.config.element_size, standardize=True, reshape=False)
+
+        ipt, orig_ipt = parse(acts), parse(orig_acts)
+        assert ipt.channels_dim == 1
+        batches = [x.to(device).view(x.shape[0], -1) for x in ipt.data]
+        orig_batches = batches if orig_ipt is None else [x.to(device).view(x.shape[0], -1) for x in orig_ipt.data]
+        weights = [w.detach().data.to(device) for w in wgts]
+        originals = weights if not orig_wgts else [w.to(device) for _, w in orig_wgts]
+        assert len(originals) == len(weights)
+        assert all(w.ndim == 2 for w in weights), "ProductsError for inputs takes the weights of linear modules"
+
+        def products(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+            if layer:
+                return torch.matmul(x, w.t()).view(1, -1)
+            xg = x.view(-1, CG, g).transpose(0, 1)  # [CG, n, g]
+            wg = w.view(w.shape[0], CG, g).permute(1, 2, 0)  # [CG, g, R]
+            return torch.bmm(xg, wg.to(x.dtype)).view(CG, -1)
+
+        base = [[products(x, w) for x in orig_batches] for w in originals]
+
+        def score(candidate: DynamicRange) -> torch.Tensor:
+            total = None
+            processed = [self.quantizer.quantize(x, kernel=None, channels_dim=None, dynamic_range=candidate,
+                                                 default_dtype=x.dtype, develop_dtype=self.develop_dtype).data
+                         for x in batches]
+            for w, y0s in zip(weights, base):
+                for x, y0 in zip(processed, y0s, strict=True):
+                    total = engine.product_error(products(x, w), y0, degree, out=total)
+            return total.view(self.error_shape)
 
         return score
 

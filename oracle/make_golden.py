@@ -974,8 +974,42 @@ RANGE_ACTS_CASES = {
 }
 
 
-@torch.no_grad()
+RANGE_ACTS_PLAN = [
+    # (quantizer case, dtype, tensor type, objective, granularity, strategy, static, allow_scale, degree, grids)
+    ("sint8_tnsr", "bf16", "Inputs", "TensorError", "Group", "GridSearch", True, False, 2, 20),
+    ("uint4_post_g32", "f16", "Inputs", "TensorError", "Group", "GridSearch", True, False, 2.4, 20),
+    ("sint4_g32", "bf16", "Inputs", "TensorError", "ChannelGroup", "GridSearch", True, False, 2, 20),
+    ("uint4_post_g32", "bf16", "Inputs", "TensorError", "Layer", "GridSearch", True, False, 2, 20),
+    ("sint8_tnsr", "f32", "Inputs", "OutputsError", "Layer", "GridSearch", True, False, 2, 20),
+    ("uint8_pre_tnsr", "bf16", "Inputs", "OutputsError", "Layer", "GridSearch", True, False, 2, 12),
+    ("sint8_tnsr_defs", "f16", "Outputs", "OutputsError", "Layer", "Manual", True, False, 2, 20),
+    ("sint8_tnsr", "f32", "Outputs", "OutputsError", "Layer", "GridSearch", True, False, 2, 20),
+    ("uint4_post_g32", "f32", "Outputs", "TensorError", "Group", "GridSearch", True, False, 2, 12),
+    ("sint8_token", "f32", "Inputs", "OutputsError", "Layer", "GridSearch", False, False, 2, 12),
+    ("sint8_token", "f32", "Inputs", "OutputsError", "Layer", "GridSearch", False, True, 2, 12),
+    ("sint4_g32", "bf16", "Inputs", "TensorError", "Layer", "GridSearch", False, True, 2, 12),
+]
+RANGE_ACTS_PRODUCTS_PLAN = [
+    # x-w products of the linears that take the input (calib/search.py:871-901, 947-973)
+    ("sint8_tnsr", "f32", "Inputs", "ProductsError", "ChannelGroup", "GridSearch", True, False, 2, 12),
+    ("sint4_g32", "f32", "Inputs", "ProductsError", "ChannelGroup", "GridSearch", True, False, 2, 12),
+    ("uint4_post_g32", "f16", "Inputs", "ProductsError", "ChannelGroup", "GridSearch", True, False, 2, 12),
+    ("uint4_post_g32", "f32", "Inputs", "ProductsError", "Group", "GridSearch", True, False, 2, 12),
+    ("sint8_token", "f32", "Inputs", "ProductsError", "ChannelGroup", "GridSearch", False, True, 2, 12),
+    ("sint4_g32", "f32", "Inputs", "ProductsError", "Group", "GridSearch", False, False, 2, 12),
+]
+
+
 def gen_range_acts(ref) -> None:
+    _gen_range_acts(ref, RANGE_ACTS_PLAN, "range_acts", 0)
+
+
+def gen_range_acts_products(ref) -> None:
+    _gen_range_acts(ref, RANGE_ACTS_PRODUCTS_PLAN, "range_acts_products", 100)
+
+
+@torch.no_grad()
+def _gen_range_acts(ref, plan, fname, first_index) -> None:
     """Range search of activations (calib/range.py:101-150, calib/search.py:839-1078): static ranges of a module's
     inputs scored on the tensor itself or on an evaluation module's outputs, static ranges of a module's outputs,
     and the clamp / ratio search of dynamically quantized inputs."""
@@ -1002,23 +1036,8 @@ def gen_range_acts(ref) -> None:
 
     DynamicRangeCalibrator._tell = tell
     try:
-        # (quantizer case, dtype, tensor type, objective, granularity, strategy, static, allow_scale, degree, grids)
-        plan = [
-            ("sint8_tnsr", "bf16", "Inputs", "TensorError", "Group", "GridSearch", True, False, 2, 20),
-            ("uint4_post_g32", "f16", "Inputs", "TensorError", "Group", "GridSearch", True, False, 2.4, 20),
-            ("sint4_g32", "bf16", "Inputs", "TensorError", "ChannelGroup", "GridSearch", True, False, 2, 20),
-            ("uint4_post_g32", "bf16", "Inputs", "TensorError", "Layer", "GridSearch", True, False, 2, 20),
-            ("sint8_tnsr", "f32", "Inputs", "OutputsError", "Layer", "GridSearch", True, False, 2, 20),
-            ("uint8_pre_tnsr", "bf16", "Inputs", "OutputsError", "Layer", "GridSearch", True, False, 2, 12),
-            ("sint8_tnsr_defs", "f16", "Outputs", "OutputsError", "Layer", "Manual", True, False, 2, 20),
-            ("sint8_tnsr", "f32", "Outputs", "OutputsError", "Layer", "GridSearch", True, False, 2, 20),
-            ("uint4_post_g32", "f32", "Outputs", "TensorError", "Group", "GridSearch", True, False, 2, 12),
-            ("sint8_token", "f32", "Inputs", "OutputsError", "Layer", "GridSearch", False, False, 2, 12),
-            ("sint8_token", "f32", "Inputs", "OutputsError", "Layer", "GridSearch", False, True, 2, 12),
-            ("sint4_g32", "bf16", "Inputs", "TensorError", "Layer", "GridSearch", False, True, 2, 12),
-        ]
         channels, hidden = 64, 96
-        for idx, (cname, dt, ttype, objective, gran, strategy, static, allow_scale, degree, grids) in enumerate(plan):
+        for idx, (cname, dt, ttype, objective, gran, strategy, static, allow_scale, degree, grids) in enumerate(plan, first_index):
             case = RANGE_ACTS_CASES[cname]
             g = torch.Generator().manual_seed(5000 + idx)
             tdt = TORCH_DT[dt]
@@ -1079,8 +1098,8 @@ def gen_range_acts(ref) -> None:
             print(" ", tag, "->", raised or "ok")
     finally:
         DynamicRangeCalibrator._tell = orig_tell
-    np.savez_compressed(os.path.join(OUT, "range_acts.npz"), **arrays)
-    with open(os.path.join(OUT, "range_acts.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, f"{fname}.npz"), **arrays)
+    with open(os.path.join(OUT, f"{fname}.json"), "w") as f:
         json.dump(dict(cases=RANGE_ACTS_CASES, entries=meta), f, indent=1)
 
 
@@ -1513,7 +1532,7 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
