@@ -1,5 +1,5 @@
 """Nunchaku (SVDQuant inference engine) weight conversion
-(reference: deepcompressor/backend/nunchaku/utils.py:16-330, backend/utils.py:12-58, 81-157).
+(reference: deepcompressor/backend/nunchaku/utils.py:16-368, backend/utils.py:12-58, 81-157).
 
 W4A4 (integer or float4 codes, per-group scales, optional two-level micro scales, low-rank branch) and W8A8 linear
 tensors in the back end's fragment order.  The code regrouping + bit packing is one HIP kernel
@@ -14,9 +14,10 @@ import typing as tp
 import torch
 
 from .._lib import DcqError, check, lib, stream_of
+from .tinychat import convert_to_tinychat_w4x16y16_linear_weight
 
 __all__ = ["ceil_divide", "pad", "fp_quantize", "NunchakuWeightPacker", "convert_to_nunchaku_w4x4y16_linear_weight",
-           "convert_to_nunchaku_w8x8y16_linear_weight", "convert_to_nunchaku_w4x4y16_linear_state_dict"]
+           "convert_to_nunchaku_w8x8y16_linear_weight", "convert_to_nunchaku_w4x4y16_linear_state_dict", "convert_to_nunchaku_w4x16_linear_weight"]
 
 
 def ceil_divide(x: int, divisor: int) -> int:
@@ -318,3 +319,30 @@ def convert_to_nunchaku_w4x4y16_linear_state_dict(weight: torch.Tensor, scale: t
     if lora is not None:
         out["lora_down"], out["lora_up"] = lora
     return out
+
+
+def convert_to_nunchaku_w4x16_linear_weight(weight: torch.Tensor, scale: torch.Tensor,
+                                            zero: torch.Tensor | None = None, bias: torch.Tensor | None = None,
+                                            adanorm_splits: int = 1):
+    """(weight int32, scale, zero, bias) of a W4A16 linear in the TinyChat layout, as Nunchaku's AdaNorm layers take
+    it (nunchaku/utils.py:341-368): the output channels of the ``adanorm_splits`` chunks are interleaved, and the
+    scale chunks' bias gets the "1 +" of the modulation folded in."""
+    oc, ic = weight.shape
+    assert scale.ndim == 4, "scale tensor should be 4D."
+    assert scale.shape[0] == oc
+    assert scale.shape[1] == scale.shape[3] == 1
+    ng = scale.shape[2]
+    if bias is None:
+        bias = torch.zeros([oc], dtype=weight.dtype, device=weight.device)
+    assert oc % adanorm_splits == 0, "output channel size should be divisible by splits."
+    if adanorm_splits > 1:
+        weight = weight.view(adanorm_splits, oc // adanorm_splits, ic).transpose(0, 1).reshape(oc, ic)
+        scale = scale.view(adanorm_splits, oc // adanorm_splits, ng).transpose(0, 1).reshape(oc, 1, ng, 1)
+        bias = bias.reshape(adanorm_splits, oc // adanorm_splits).transpose(0, 1)
+        delta = [0] * adanorm_splits
+        delta[1] = delta[-2] = 1
+        bias = bias.add_(torch.tensor(delta, dtype=bias.dtype, device=bias.device))
+        bias = bias.reshape(oc)
+    weight, scale, zero = convert_to_tinychat_w4x16y16_linear_weight(
+        weight=weight, scale=scale, zero=torch.full_like(scale, 7) if zero is None else zero, zero_pre_scaled=True)
+    return weight.view(torch.int32), scale, zero, bias
