@@ -8,7 +8,8 @@ from ...utils.config import SkipBasedConfig, configclass
 from .search import (SearchBasedCalibConfig, SearchBasedCalibGranularity, SearchBasedCalibObjective,
                      SearchBasedCalibStrategy)
 
-__all__ = ["SmoothSpanMode", "SmoothCalibConfig", "SmoothAttentionCalibConfig", "SkipBasedSmoothCalibConfig"]
+__all__ = ["SmoothSpanMode", "SmoothCalibConfig", "SmoothAttentionCalibConfig", "SkipBasedSmoothCalibConfig",
+           "SmoothTransfomerConfig"]
 
 
 class SmoothSpanMode(enum.Enum):
@@ -142,3 +143,34 @@ class SmoothAttentionCalibConfig(SmoothCalibConfig):
     element_size: int = field(init=False, default=-1)
     pre_reshape: bool = field(init=False, default=True)
     allow_low_rank: bool = field(init=False, default=False)
+
+
+@configclass
+@dataclass
+class SmoothTransfomerConfig:
+    """Smoothing of a transformer block (calib/config/smooth.py:349-400): ``proj`` for the linears fed by one
+    activation, ``attn`` for the query-key product."""
+
+    proj: SkipBasedSmoothCalibConfig | None = None
+    attn: SmoothAttentionCalibConfig | None = None
+
+    @property
+    def enabled_proj(self) -> bool:
+        return self.proj is not None
+
+    @property
+    def enabled_attn(self) -> bool:
+        return self.attn is not None
+
+    def generate_dirnames(self, *, prefix: str = "", **kwargs) -> list[str]:
+        proj_names = self.proj.generate_dirnames(prefix="proj") if self.proj is not None else []
+        attn_names = self.attn.generate_dirnames(prefix="attn") if self.attn is not None else []
+        names = []
+        for index in range(max(len(proj_names), len(attn_names))):
+            name = []
+            if index < len(proj_names):
+                name.append(proj_names[index])
+            if index < len(attn_names):
+                name.append(attn_names[index])
+            names.append("-".join(name))
+        return [f"{prefix}.{name}" for name in names] if prefix else names

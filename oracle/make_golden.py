@@ -1556,6 +1556,137 @@ def gen_tinychat(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+TINY_LLAMA = dict(vocab_size=128, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                  num_key_value_heads=2, max_position_embeddings=64)
+
+
+def gen_llm_layer_stages(ref) -> None:
+    """The reference's rotation and smoothing stages (app/llm/quant/rotate.py:25-196, app/llm/quant/smooth.py:23-167)
+    run on a two-layer random Llama (bf16, grouped-query attention): every parameter before and after the rotation,
+    the first layer's cached activations, and the smoothing scales and parameters after the QoQ-style manual smoothing
+    and after a grid search on the output / down projections."""
+    import types
+
+    from deepcompressor.app.llm.nn.struct import LlmModelStruct
+    from deepcompressor.app.llm.quant.quantizer.config import LlmActivationQuantizerConfig, LlmWeightQuantizerConfig
+    from deepcompressor.app.llm.quant.rotate import rotate_llm
+    from deepcompressor.app.llm.quant.smooth import smooth_llm_layer
+    from deepcompressor.calib.config import SearchBasedCalibStrategy
+    from deepcompressor.calib.config.rotation import QuantRotationConfig
+    from deepcompressor.calib.config.smooth import (
+        SkipBasedSmoothCalibConfig,
+        SmoothAttentionCalibConfig,
+        SmoothSpanMode,
+        SmoothTransfomerConfig,
+    )
+    from deepcompressor.data.cache import IOTensorsCache, TensorCache
+    from deepcompressor.data.dtype import QuantDataType
+    from deepcompressor.data.utils.reshape import LinearReshapeFn
+    from deepcompressor.data.zero import ZeroPointDomain
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    arrays, meta = {}, dict(model=TINY_LLAMA)
+    bits = lambda t: t.detach().contiguous().view(torch.int16).numpy().copy()  # noqa: E731  (bf16 bit patterns)
+
+    def put_state(tag, model):
+        for k, v in model.state_dict().items():
+            arrays[f"{tag}|{k}"] = bits(v) if v.dtype == torch.bfloat16 else v.numpy().copy()
+
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(LlamaConfig(**TINY_LLAMA, attn_implementation="eager")).to(torch.bfloat16).eval()
+    # norms away from one and channels of unequal size, so that folding and smoothing have something to do
+    g = torch.Generator().manual_seed(11)
+    for name, p in model.named_parameters():
+        if "layernorm" in name or name.endswith("norm.weight"):
+            p.data = (torch.rand(p.shape, generator=g) + 0.5).to(torch.bfloat16)
+    model.model.embed_tokens.weight.data = (model.model.embed_tokens.weight.data.float()
+                                            * torch.exp(torch.randn(64, generator=g))).to(torch.bfloat16)
+    put_state("init", model)
+    tokens = [torch.randint(0, 128, (2, 16), generator=torch.Generator().manual_seed(s)) for s in (1, 2)]
+    arrays["tokens"] = torch.stack(tokens).numpy()
+    with torch.no_grad():
+        arrays["logits|init"] = model(tokens[0]).logits.float().numpy()
+    struct = LlmModelStruct.construct(model)
+    rotation = rotate_llm(struct, QuantRotationConfig(random=False, transforms=["out_proj"]))
+    arrays["rotation"] = rotation.numpy().copy()
+    put_state("rotated", model)
+    with torch.no_grad():
+        arrays["logits|rotated"] = model(tokens[0]).logits.float().numpy()
+    layer = struct.backbone_struct.layer_structs[0]
+    attn, ffn = layer.attn_struct, layer.ffn_struct
+    store: dict[str, dict] = {}
+
+    def grab(name, module):
+        def pre(mod, args, kwargs):
+            d = store.setdefault(name, dict(inputs=[], outputs=[], kwargs=None))
+            d["inputs"].append((args[0] if args else kwargs["hidden_states"]).detach().clone())
+            if d["kwargs"] is None:
+                d["kwargs"] = {k: v for k, v in kwargs.items() if k != "hidden_states"}
+
+        def post(mod, args, out):
+            store[name]["outputs"].append((out[0] if isinstance(out, tuple) else out).detach().clone())
+
+        return [module.register_forward_pre_hook(pre, with_kwargs=True), module.register_forward_hook(post)]
+
+    hooks = []
+    watched = [(attn.name, attn.module), (attn.q_proj_name, attn.q_proj), (attn.k_proj_name, attn.k_proj),
+               (attn.o_proj_name, attn.o_proj), (ffn.name, ffn.module), (ffn.down_proj_names[0], ffn.down_projs[0])]
+    for name, mod in watched:
+        hooks += grab(name, mod)
+    with torch.no_grad():
+        for t in tokens:
+            model(t)
+    for h in hooks:
+        h.remove()
+    for name, d in store.items():
+        arrays[f"acts|{name}|inputs"] = np.stack([bits(x) for x in d["inputs"]])
+        arrays[f"acts|{name}|outputs"] = np.stack([bits(x) for x in d["outputs"]])
+    meta["watched"] = [name for name, _ in watched]
+    # what the attention block takes besides the hidden states (the same for every batch: same length, no padding)
+    captured = store[attn.name]["kwargs"]
+    layer_kwargs = dict(attention_mask=captured["attention_mask"], position_embeddings=captured["position_embeddings"])
+    mask, (cos, sin) = layer_kwargs["attention_mask"], layer_kwargs["position_embeddings"]
+    arrays["kwargs|attention_mask"] = mask.float().numpy()
+    arrays["kwargs|cos"], arrays["kwargs|sin"] = cos.float().numpy(), sin.float().numpy()
+    meta["kwargs_dtypes"] = dict(attention_mask=str(mask.dtype), cos=str(cos.dtype), sin=str(sin.dtype))
+
+    def tc(ts):
+        return TensorCache([t.clone() for t in ts], channels_dim=-1, reshape=LinearReshapeFn(), num_cached=len(ts),
+                           num_total=len(ts), num_samples=len(ts) * ts[0].shape[0])
+
+    layer_cache = {name: IOTensorsCache(inputs=tc(d["inputs"]), outputs=tc(d["outputs"])) for name, d in store.items()}
+    wg = LlmWeightQuantizerConfig(dtype=QuantDataType.from_str("uint4"), zero_point=ZeroPointDomain.PostScale,
+                                  group_shapes=((1, 16),), scale_dtypes=(torch.float16,))
+    ip = LlmActivationQuantizerConfig(dtype=QuantDataType.from_str("sint8"), zero_point=None, group_shapes=((1, -1),),
+                                      scale_dtypes=(torch.float16,))
+    op = LlmActivationQuantizerConfig(dtype=QuantDataType.from_str("uint4"), zero_point=ZeroPointDomain.PostScale,
+                                      group_shapes=((1, 16),), scale_dtypes=(torch.float16,), skips=["attn_q"])
+    spans = [(SmoothSpanMode.AbsMax, SmoothSpanMode.AbsMax)]
+    rotated = {k: v.clone() for k, v in model.state_dict().items()}
+    plans = {
+        "manual": (SkipBasedSmoothCalibConfig(strategy=SearchBasedCalibStrategy.Manual, spans=spans, alpha=0.3, beta=0.7,
+                                              skips=[]),
+                   SmoothAttentionCalibConfig(strategy=SearchBasedCalibStrategy.Manual, spans=spans, alpha=0.5, beta=0)),
+        "grid": (SkipBasedSmoothCalibConfig(strategy=SearchBasedCalibStrategy.GridSearch, spans=spans, alpha=0.5, beta=-2,
+                                            num_grids=4, skips=["qkv_proj", "up_proj"]), None),
+    }
+    for tag, (proj, att) in plans.items():
+        model.load_state_dict(rotated)
+        cfg = types.SimpleNamespace(wgts=wg, ipts=ip, opts=op, enabled_wgts=True, enabled_ipts=True, enabled_opts=True,
+                                    smooth=SmoothTransfomerConfig(proj=proj, attn=att), develop_dtype=torch.float32)
+        cache: dict[str, torch.Tensor] = {}
+        smooth_llm_layer(layer, cfg, cache, layer_cache=layer_cache, layer_kwargs=layer_kwargs)
+        for k, v in cache.items():
+            arrays[f"smooth|{tag}|scale|{k}"] = v.float().numpy().copy()
+        put_state(f"smooth|{tag}|state", model)
+        with torch.no_grad():
+            arrays[f"logits|smooth|{tag}"] = model(tokens[0]).logits.float().numpy()
+        meta[f"smooth|{tag}"] = dict(scales=sorted(cache))
+    np.savez_compressed(os.path.join(OUT, "llm_layer_stages.npz"), **arrays)
+    with open(os.path.join(OUT, "llm_layer_stages.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 FP_ZERO_CASES = {
     # floating-point types with a zero point: the range is centred on the group mean (data/range.py:323-341)
     "sfp4_post_g32": dict(dtype="sfp4_e2m1_all", zero="PostScale", groups=((1, 32),), sdt=("f16",), shape=(32, 256)),
@@ -1592,7 +1723,7 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "tinychat"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "tinychat", "llm_layer_stages"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)

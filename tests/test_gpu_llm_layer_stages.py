@@ -1,0 +1,121 @@
+"""Rotation and smoothing stages on the GPU (``rotate_llm``, ``smooth_llm_layer``) against the reference's own stage
+drivers run on a two-layer random Llama.
+
+Bars: rotation -- every parameter within 1 bfloat16 ulp of the reference's, >= 99.9 % identical (float64 products
+summed in another order); smoothing scales <= 4 ulp (quotients of float32 powers); parameters after manual smoothing
+identical wherever the scale is; the grid search picks the reference's candidates (scales <= 4 ulp)."""
+
+import numpy as np
+import pytest
+import torch
+from _tiny_llama import bf16_from_bits, build, state_of
+from test_oracle_llm_layer_stages import LS, ulp_bf16, values
+
+from deepcompressor_amd.app import (LlmActivationQuantizerConfig, LlmModelStruct, LlmQuantConfig,
+                                    LlmWeightQuantizerConfig, rotate_llm, smooth_llm_layer)
+from deepcompressor_amd.calib.config import (QuantRotationConfig, SearchBasedCalibStrategy, SkipBasedSmoothCalibConfig,
+                                             SmoothAttentionCalibConfig, SmoothSpanMode, SmoothTransfomerConfig)
+from deepcompressor_amd.data.cache import IOTensorsCache, TensorCache
+from deepcompressor_amd.data.dtype import QDType
+from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
+from deepcompressor_amd.data.zero import ZeroPointDomain
+
+pytestmark = pytest.mark.gpu
+pytest.importorskip("transformers")
+
+
+def host_state(model):
+    return {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items() if "rotary" not in k}
+
+
+def test_rotation_stage_matches_reference():
+    model = build(LS, "init", "cuda")
+    tokens = torch.from_numpy(LS["tokens"][0]).cuda()
+    rotation = rotate_llm(model, QuantRotationConfig(random=False, transforms=["out_proj"]))
+    np.testing.assert_array_equal(rotation.cpu().numpy(), LS["rotation"])
+    got, want = host_state(model), values("rotated")
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert model.state_dict()[k].dtype == torch.bfloat16, k
+        u = ulp_bf16(got[k], want[k])
+        assert u.max() <= 1 and (u == 0).mean() >= 0.999, (k, u.max(), (u == 0).mean())
+    with torch.no_grad():
+        logits = model(tokens).logits.float().cpu().numpy()
+    assert np.abs(logits - LS["logits|init"]).max() <= 0.03 * np.abs(LS["logits|init"]).max()  # the function is kept
+
+
+def smoothing_inputs(model):
+    struct = LlmModelStruct.construct(model)
+    layer = struct.backbone_struct.layer_structs[0]
+
+    def cache(name, side):
+        ts = [bf16_from_bits(a).cuda() for a in LS[f"acts|{name}|{side}"]]
+        return TensorCache(ts, channels_dim=-1, reshape=LinearReshapeFn(), num_cached=len(ts), num_total=len(ts),
+                           num_samples=len(ts) * ts[0].shape[0], orig_device=torch.device("cuda"))
+
+    layer_cache = {name: IOTensorsCache(inputs=cache(name, "inputs"), outputs=cache(name, "outputs"))
+                   for name in LS.meta["watched"]}
+    bf = lambda key: torch.from_numpy(LS[key]).to(torch.bfloat16).cuda()  # noqa: E731
+    kwargs = dict(attention_mask=bf("kwargs|attention_mask"), position_embeddings=(bf("kwargs|cos"), bf("kwargs|sin")))
+    return layer, layer_cache, kwargs
+
+
+def quant_config(proj, attn):
+    f16 = (torch.float16,)
+    return LlmQuantConfig(
+        wgts=LlmWeightQuantizerConfig(dtype=QDType.uint4, zero_point=ZeroPointDomain.PostScale, group_shapes=((1, 16),),
+                                      scale_dtypes=f16),
+        ipts=LlmActivationQuantizerConfig(dtype=QDType.sint8, zero_point=None, group_shapes=((1, -1),), scale_dtypes=f16),
+        opts=LlmActivationQuantizerConfig(dtype=QDType.uint4, zero_point=ZeroPointDomain.PostScale,
+                                          group_shapes=((1, 16),), scale_dtypes=f16, skips=["attn_q"]),
+        smooth=SmoothTransfomerConfig(proj=proj, attn=attn))
+
+
+SPANS = [(SmoothSpanMode.AbsMax, SmoothSpanMode.AbsMax)]
+
+
+def check_scales(tag, cache):
+    assert sorted(cache) == LS.meta[f"smooth|{tag}"]["scales"]
+    for k, v in cache.items():
+        want = LS[f"smooth|{tag}|scale|{k}"]
+        assert v.device.type == "cpu" and v.dtype == torch.float32
+        assert (np.abs(v.numpy().astype(np.float64) - want) <= 4 * np.spacing(want)).all(), k
+
+
+def test_manual_smoothing_stage_matches_reference():
+    model = build(LS, "rotated", "cuda")
+    layer, layer_cache, kwargs = smoothing_inputs(model)
+    config = quant_config(
+        SkipBasedSmoothCalibConfig(strategy=SearchBasedCalibStrategy.Manual, spans=SPANS, alpha=0.3, beta=0.7, skips=[]),
+        SmoothAttentionCalibConfig(strategy=SearchBasedCalibStrategy.Manual, spans=SPANS, alpha=0.5, beta=0))
+    cache: dict[str, torch.Tensor] = {}
+    smooth_llm_layer(layer, config, cache, layer_cache=layer_cache, layer_kwargs=kwargs)
+    check_scales("manual", cache)
+    got, want = host_state(model), values("smooth|manual|state")
+    for k in want:
+        u = ulp_bf16(got[k], want[k])  # a scale 1 ulp off moves a scaled weight onto the next bfloat16 value at most
+        assert u.max() <= 1 and (u == 0).mean() >= 0.97, (k, u.max(), (u == 0).mean())
+    # applying the stored scales to a fresh copy needs no activations and gives the same parameters
+    again = build(LS, "rotated", "cuda")
+    smooth_llm_layer(LlmModelStruct.construct(again).backbone_struct.layer_structs[0], config, dict(cache))
+    for k, v in host_state(again).items():
+        np.testing.assert_array_equal(v, got[k], err_msg=k)
+    tokens = torch.from_numpy(LS["tokens"][0]).cuda()
+    with torch.no_grad():
+        logits = model(tokens).logits.float().cpu().numpy()
+    assert np.abs(logits - LS["logits|rotated"]).max() <= 0.03 * np.abs(LS["logits|rotated"]).max()
+
+
+def test_grid_smoothing_stage_picks_the_reference_candidates():
+    model = build(LS, "rotated", "cuda")
+    layer, layer_cache, kwargs = smoothing_inputs(model)
+    config = quant_config(
+        SkipBasedSmoothCalibConfig(strategy=SearchBasedCalibStrategy.GridSearch, spans=SPANS, alpha=0.5, beta=-2,
+                                   num_grids=4, skips=["qkv_proj", "up_proj"]), None)
+    cache: dict[str, torch.Tensor] = {}
+    smooth_llm_layer(layer, config, cache, layer_cache=layer_cache, layer_kwargs=kwargs)
+    check_scales("grid", cache)
+    got, want = host_state(model), values("smooth|grid|state")
+    for k in want:
+        u = ulp_bf16(got[k], want[k])
+        assert u.max() <= 1 and (u == 0).mean() >= 0.97, (k, u.max(), (u == 0).mean())
