@@ -1,5 +1,6 @@
-"""Rotation and smoothing stages of a decoder-only language model
-(reference: deepcompressor/app/llm/quant/rotate.py:25-196, app/llm/quant/smooth.py:23-167).
+"""Rotation, channel-reorder and smoothing stages of a decoder-only language model
+(reference: deepcompressor/app/llm/quant/rotate.py:25-196, app/llm/quant/reorder.py:48-236,
+app/llm/quant/smooth.py:23-167).
 
 The drivers walk struct objects (``llm_struct``, or the reference's own -- the attribute names are the same) and call
 the building blocks of ``calib.rotate`` / ``calib.smooth``; all arithmetic runs on the device the modules live on.
@@ -16,6 +17,7 @@ import torch.nn as nn
 from ..calib.config.reorder import SkipBasedChannelOrderConfig
 from ..calib.config.rotation import QuantRotationConfig
 from ..calib.config.smooth import SmoothTransfomerConfig
+from ..calib.reorder import ChannelOrderCalibrator, ChannelReorderer
 from ..calib.rotate import (get_rotation_matrix, hadamard_in_channels, rotate_in_channels, rotate_out_channels,
                             transform_norm_and_linear)
 from ..calib.smooth import ActivationSmoother, smooth_attention, smooth_linear_modules
@@ -24,7 +26,7 @@ from ..quantizer.processor import Quantizer
 from .llm import LlmActivationQuantizerConfig, LlmWeightQuantizerConfig
 from .llm_struct import LlmModelStruct, LlmTransformerBlockStruct
 
-__all__ = ["LlmQuantConfig", "rotate_llm", "smooth_llm_layer"]
+__all__ = ["LlmQuantConfig", "rotate_llm", "reorder_llm_layer", "smooth_llm_layer"]
 
 
 @dataclass
@@ -235,3 +237,112 @@ def smooth_llm_layer(layer: LlmTransformerBlockStruct, config: LlmQuantConfig, s
                 config=config.smooth.proj, weight_quantizer=Quantizer(config.wgts, key=ffn.down_proj_key),
                 input_quantizer=Quantizer(config.ipts, channels_dim=-1, key=ffn.down_proj_key), inputs=io(cache_key),
                 eval_inputs=io(cache_key), eval_module=ffn.down_projs[expert_idx], develop_dtype=dev_dtype)
+
+
+@torch.inference_mode()
+def reorder_llm_layer(layer: LlmTransformerBlockStruct, config: LlmQuantConfig, reorder_cache: dict[str, torch.Tensor],
+                      residual_calibrator: ChannelOrderCalibrator | None = None,
+                      layer_cache: dict[str, IOTensorsCache] | None = None,
+                      layer_kwargs: dict[str, tp.Any] | None = None) -> ChannelOrderCalibrator | None:
+    """Find (or take from ``reorder_cache``) and apply the input-channel orders inside one decoder layer
+    (reorder.py:48-236): the output projection (its order, reduced to the key/value heads, also permutes v_proj's
+    rows) and every down projection (permuting the rows of its up projections); with ``dynamic`` orders also the
+    q/k/v and up projections, whose inputs are then permuted at run time by a hook.  Returns the calibrator that
+    collects the residual stream's channel metrics, or None once it is of no use."""
+    layer_cache, layer_kwargs = layer_cache or {}, layer_kwargs or {}
+    attn, ffn = layer.attn_struct, layer.ffn_struct
+    qkv_proj, out_proj = attn.qkv_proj, attn.out_proj
+    num_heads, num_head_repeats = attn.config.num_query_heads, attn.config.num_head_repeats
+
+    def inputs(name: str):
+        return layer_cache[name].inputs if layer_cache else None
+
+    def keep(index: torch.Tensor | None, channels: int) -> torch.Tensor:
+        # a search that the given order wins hands back None (the reference's driver then fails on ``None.to``,
+        # reorder.py:104, 133, 179, 208); here that is stored as the identity order
+        return (torch.arange(channels) if index is None else index).to(device=torch.device("cpu"))
+
+    def calibrator(key: str, **heads) -> ChannelOrderCalibrator:
+        return ChannelOrderCalibrator(config=config.reorder, weight_quantizer=Quantizer(config.wgts, key=key),
+                                      input_quantizer=Quantizer(config.ipts, channels_dim=-1, key=key),
+                                      develop_dtype=config.develop_dtype, **heads)
+
+    if config.reorder.dynamic and config.reorder.is_enabled_for(attn.qkv_proj_key):
+        cache_key = attn.name
+        if cache_key not in reorder_cache:
+            index = calibrator(attn.qkv_proj_key).calibrate(
+                x_wgts=[m.weight for m in qkv_proj], x_acts=inputs(attn.v_proj_name), x_mods=qkv_proj,
+                eval_inputs=inputs(cache_key), eval_module=attn.module, eval_kwargs=attn.filter_kwargs(layer_kwargs),
+                reorder_wgts=[(m.weight, 1) for m in qkv_proj], reorder_ipt_mods=[(attn.module, -1, None)],
+                reorder_opt_mods=[])
+            reorder_cache[cache_key] = keep(index, qkv_proj[0].weight.shape[1])
+        index = reorder_cache[cache_key]
+        for proj in qkv_proj:
+            proj.weight.data = proj.weight.data.index_select(1, index.to(proj.weight.device))
+        ChannelReorderer(index, channels_dim=-1).as_hook().register(attn.module)
+    if config.reorder.is_enabled_for(attn.out_proj_key):
+        cache_key = attn.out_proj_name
+        if cache_key not in reorder_cache:
+            index = calibrator(attn.out_proj_key, num_heads=num_heads, num_head_repeats=num_head_repeats).calibrate(
+                x_wgts=[out_proj.weight], x_acts=inputs(cache_key), x_mods=[out_proj], eval_inputs=inputs(cache_key),
+                eval_module=out_proj, reorder_wgts=[(out_proj.weight, 1)], reorder_ipt_mods=[(out_proj, -1, None)],
+                reorder_opt_mods=[])
+            reorder_cache[cache_key] = keep(index, out_proj.weight.shape[1])
+        index = reorder_cache[cache_key].to(out_proj.weight.device)
+        out_proj.weight.data = out_proj.weight.data.index_select(1, index)
+        v_proj = qkv_proj[2]
+        if num_heads > 1 and num_head_repeats > 1:
+            # the order inside the first query head of every group, as an order of the key/value head's channels
+            num_channels = index.numel()
+            head_channels = num_channels // num_heads
+            index = index.view(num_heads, head_channels)
+            index = index - torch.arange(0, num_channels, head_channels, device=index.device).view(num_heads, 1)
+            num_v_heads = num_heads // num_head_repeats
+            index = index.view(num_v_heads, num_head_repeats, head_channels)[:, 0, :]
+            index = index + torch.arange(0, num_channels // num_head_repeats, head_channels,
+                                         device=index.device).view(num_v_heads, 1)
+            index = index.reshape(-1)
+        v_proj.weight.data = v_proj.weight.data.index_select(0, index.to(v_proj.weight.device))
+        if v_proj.bias is not None:
+            v_proj.bias.data = v_proj.bias.data[index.to(v_proj.bias.device)].contiguous()
+    num_experts = ffn.config.num_experts
+    up_proj, down_proj = ffn.up_projs, ffn.down_projs
+    if config.reorder.dynamic and config.reorder.is_enabled_for(ffn.up_proj_key):
+        cache_key = ffn.name
+        if cache_key not in reorder_cache:
+            index = calibrator(ffn.up_proj_key).calibrate(
+                x_wgts=[m.weight for m in up_proj], x_acts=inputs(cache_key), x_mods=up_proj,
+                eval_inputs=inputs(cache_key), eval_module=ffn.module, reorder_wgts=[(m.weight, 1) for m in up_proj],
+                reorder_ipt_mods=[(ffn.module, -1, None)], reorder_opt_mods=[])
+            reorder_cache[cache_key] = keep(index, up_proj[0].weight.shape[1])
+        index = reorder_cache[cache_key]
+        for fc in up_proj:
+            fc.weight.data = fc.weight.data.index_select(1, index.to(fc.weight.device))
+        if ffn.moe_gate is not None:
+            ffn.moe_gate.weight.data = ffn.moe_gate.weight.data.index_select(1, index.to(ffn.moe_gate.weight.device))
+        ChannelReorderer(index, channels_dim=-1).as_hook().register(ffn.module)
+    if config.reorder.is_enabled_for(ffn.down_proj_key):
+        for expert_idx, (fc2_name, fc2) in enumerate(zip(ffn.down_proj_names, down_proj, strict=True)):
+            cache_key = fc2_name
+            if cache_key not in reorder_cache:
+                index = calibrator(ffn.down_proj_key).calibrate(
+                    x_wgts=[fc2.weight], x_acts=inputs(cache_key), x_mods=[fc2], eval_inputs=inputs(cache_key),
+                    eval_module=fc2, reorder_wgts=[(fc2.weight, 1)], reorder_ipt_mods=[(fc2, -1, None)],
+                    reorder_opt_mods=[])
+                reorder_cache[cache_key] = keep(index, fc2.weight.shape[1])
+            index = reorder_cache[cache_key].to(fc2.weight.device)
+            fc2.weight.data = fc2.weight.data.index_select(1, index)
+            for fc1 in up_proj[expert_idx::num_experts]:
+                fc1.weight.data = fc1.weight.data.index_select(0, index.to(fc1.weight.device))
+                if fc1.bias is not None:
+                    fc1.bias.data = fc1.bias.data[index.to(fc1.bias.device)].contiguous()
+    if residual_calibrator is not None and (config.reorder.dynamic
+                                            or not config.reorder.is_enabled_for(attn.qkv_proj_key)
+                                            or not config.reorder.is_enabled_for(ffn.up_proj_key)):
+        residual_calibrator = None
+    if residual_calibrator is not None and "residual" not in reorder_cache:
+        residual_calibrator.update_channel_metrics(weights=[m.weight for m in qkv_proj], inputs=inputs(attn.v_proj_name))
+        for expert_idx in range(num_experts):
+            residual_calibrator.update_channel_metrics(weights=[m.weight for m in up_proj[expert_idx::num_experts]],
+                                                       inputs=inputs(ffn.up_proj_names[expert_idx]))
+    return residual_calibrator

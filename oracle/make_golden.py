@@ -1682,6 +1682,26 @@ def gen_llm_layer_stages(ref) -> None:
         with torch.no_grad():
             arrays[f"logits|smooth|{tag}"] = model(tokens[0]).logits.float().numpy()
         meta[f"smooth|{tag}"] = dict(scales=sorted(cache))
+    # channel reorder inside the layer (app/llm/quant/reorder.py:48-236): the output projection's order with grouped
+    # query heads (also permuting v_proj's rows) and the down projection's (permuting up / gate rows)
+    from deepcompressor.app.llm.quant.reorder import reorder_llm_layer
+    from deepcompressor.calib.config.reorder import ChannelOrderCalibConfig, SkipBasedChannelOrderConfig
+
+    reorder_plans = {
+        "manual": dict(strategy=SearchBasedCalibStrategy.Manual, channel_metric=ChannelOrderCalibConfig.ChannelMetric.InputsAbsMax,
+                       channel_index=ChannelOrderCalibConfig.ChannelIndex.Sequential),
+    }
+    for tag, kw in reorder_plans.items():
+        model.load_state_dict(rotated)
+        cfg = types.SimpleNamespace(wgts=wg, ipts=ip, opts=op, enabled_wgts=True, enabled_ipts=True, enabled_opts=True,
+                                    reorder=SkipBasedChannelOrderConfig(skips=["residual"], **kw),
+                                    develop_dtype=torch.float32)
+        cache = {}
+        reorder_llm_layer(layer, cfg, cache, layer_cache=layer_cache, layer_kwargs=layer_kwargs)
+        for k, v in cache.items():
+            arrays[f"reorder|{tag}|index|{k}"] = v.numpy().copy()
+        put_state(f"reorder|{tag}|state", model)
+        meta[f"reorder|{tag}"] = dict(indexes=sorted(cache))
     np.savez_compressed(os.path.join(OUT, "llm_layer_stages.npz"), **arrays)
     with open(os.path.join(OUT, "llm_layer_stages.json"), "w") as f:
         json.dump(meta, f, indent=1)

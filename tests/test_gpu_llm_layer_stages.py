@@ -8,7 +8,7 @@ identical wherever the scale is; the grid search picks the reference's candidate
 import numpy as np
 import pytest
 import torch
-from _tiny_llama import bf16_from_bits, build, state_of
+from _tiny_llama import bf16_from_bits, bf16_values, build, state_of
 from test_oracle_llm_layer_stages import LS, ulp_bf16, values
 
 from deepcompressor_amd.app import (LlmActivationQuantizerConfig, LlmModelStruct, LlmQuantConfig,
@@ -119,3 +119,56 @@ def test_grid_smoothing_stage_picks_the_reference_candidates():
     for k in want:
         u = ulp_bf16(got[k], want[k])
         assert u.max() <= 1 and (u == 0).mean() >= 0.97, (k, u.max(), (u == 0).mean())
+
+
+def test_manual_reorder_stage_matches_reference():
+    from deepcompressor_amd.app import reorder_llm_layer
+    from deepcompressor_amd.calib.config import ChannelOrderCalibConfig, SkipBasedChannelOrderConfig
+
+    model = build(LS, "rotated", "cuda")
+    layer, layer_cache, kwargs = smoothing_inputs(model)
+    config = quant_config(None, None)
+    config.reorder = SkipBasedChannelOrderConfig(
+        skips=["residual"], strategy=SearchBasedCalibStrategy.Manual,
+        channel_metric=ChannelOrderCalibConfig.ChannelMetric.InputsAbsMax,
+        channel_index=ChannelOrderCalibConfig.ChannelIndex.Sequential)
+    cache: dict[str, torch.Tensor] = {}
+    leftover = reorder_llm_layer(layer, config, cache, layer_cache=layer_cache, layer_kwargs=kwargs)
+    assert leftover is None and sorted(cache) == LS.meta["reorder|manual"]["indexes"]
+    import reorder_oracle as rr
+    from test_oracle_llm_layer_stages import assert_same_sort, v_proj_order
+
+    rotated, got = values("rotated"), host_state(model)
+    p = "model.layers.0"
+    for k, v in cache.items():
+        assert v.device.type == "cpu" and v.dtype == torch.int64
+        # tied abs-max values (bfloat16 activations) may come out in either order: the reference's argsort is not stable
+        xs = list(bf16_values(LS[f"acts|{k}|inputs"]))
+        metric = rr.channel_metric(xs, [rotated[f"{k}.weight"]], "InputsAbsMax", v.numel())
+        assert_same_sort(metric, v.numpy(), LS[f"reorder|manual|index|{k}"])
+    o_index, d_index = cache[f"{p}.self_attn.o_proj"].numpy(), cache[f"{p}.mlp.down_proj"].numpy()
+    expect = dict(rotated)
+    expect[f"{p}.self_attn.o_proj.weight"] = rotated[f"{p}.self_attn.o_proj.weight"][:, o_index]
+    expect[f"{p}.self_attn.v_proj.weight"] = rotated[f"{p}.self_attn.v_proj.weight"][v_proj_order(o_index)]
+    expect[f"{p}.mlp.down_proj.weight"] = rotated[f"{p}.mlp.down_proj.weight"][:, d_index]
+    for n in ("up_proj", "gate_proj"):
+        expect[f"{p}.mlp.{n}.weight"] = rotated[f"{p}.mlp.{n}.weight"][d_index]
+    for k in expect:
+        np.testing.assert_array_equal(got[k], expect[k], err_msg=k)
+    # with the reference's orders handed in, the parameters are the reference's
+    ref_run = build(LS, "rotated", "cuda")
+    ref_cache = {k: torch.from_numpy(LS[f"reorder|manual|index|{k}"]) for k in cache}
+    reorder_llm_layer(LlmModelStruct.construct(ref_run).backbone_struct.layer_structs[0], config, ref_cache)
+    want = values("reorder|manual|state")
+    for k, v in host_state(ref_run).items():
+        np.testing.assert_array_equal(v, want[k], err_msg=k)
+    # a permutation of hidden channels between producer and consumer keeps the function
+    tokens = torch.from_numpy(LS["tokens"][0]).cuda()
+    with torch.no_grad():
+        logits = model(tokens).logits.float().cpu().numpy()
+    assert np.abs(logits - LS["logits|rotated"]).max() <= 0.03 * np.abs(LS["logits|rotated"]).max()
+    # stored orders are applied as they are
+    again = build(LS, "rotated", "cuda")
+    reorder_llm_layer(LlmModelStruct.construct(again).backbone_struct.layer_structs[0], config, dict(cache))
+    for k, v in host_state(again).items():
+        np.testing.assert_array_equal(v, got[k], err_msg=k)

@@ -97,3 +97,46 @@ def test_structs_name_modules_like_the_reference():
     assert ffn.up_proj_names == ["model.layers.0.mlp.up_proj", "model.layers.0.mlp.gate_proj"]
     assert attn.config.num_query_heads == HEADS and attn.config.num_head_repeats == HEADS // KV
     assert struct.num_head_channels == HC and struct.backbone_struct.num_channels == MODEL["hidden_size"]
+
+
+def v_proj_order(index: np.ndarray) -> np.ndarray:
+    """reorder.py:138-149: the order inside the first query head of every group, as an order of v_proj's rows."""
+    n = index.size
+    idx = index.reshape(HEADS, HC) - np.arange(0, n, HC).reshape(HEADS, 1)
+    idx = idx.reshape(KV, HEADS // KV, HC)[:, 0, :] + np.arange(0, n // (HEADS // KV), HC).reshape(KV, 1)
+    return idx.reshape(-1)
+
+
+def assert_same_sort(metric: np.ndarray, got: np.ndarray, want: np.ndarray) -> None:
+    assert sorted(got.tolist()) == sorted(want.tolist()) == list(range(metric.size))
+    np.testing.assert_array_equal(metric[got], metric[want])
+    values_, counts = np.unique(metric, return_counts=True)
+    unique = np.isin(metric[want], values_[counts == 1])
+    np.testing.assert_array_equal(got[unique], want[unique])
+
+
+def test_manual_reorder_stage_oracle_matches_reference():
+    import reorder_oracle as rr
+
+    state, want = values("rotated"), values("reorder|manual|state")
+    acts = lambda name: list(bf16_values(LS[f"acts|{name}|inputs"]))  # noqa: E731
+    p = "model.layers.0"
+    assert LS.meta["reorder|manual"]["indexes"] == sorted([f"{p}.self_attn.o_proj", f"{p}.mlp.down_proj"])
+    o_w = state[f"{p}.self_attn.o_proj.weight"]
+    (o_index,) = rr.candidates(acts(f"{p}.self_attn.o_proj"), [o_w], o_w.shape[1], 16, HEADS, HEADS // KV,
+                               manual=("InputsAbsMax", "Sequential"))
+    np.testing.assert_array_equal(o_index, LS[f"reorder|manual|index|{p}.self_attn.o_proj"])
+    d_w = state[f"{p}.mlp.down_proj.weight"]
+    (d_index,) = rr.candidates(acts(f"{p}.mlp.down_proj"), [d_w], d_w.shape[1], 16, manual=("InputsAbsMax", "Sequential"))
+    # bfloat16 activations tie in their abs-max; the reference's argsort is not stable, so tied channels may swap:
+    # both orders must sort the metric identically and agree wherever the metric value is unique
+    d_ref = LS[f"reorder|manual|index|{p}.mlp.down_proj"]
+    assert_same_sort(rr.channel_metric(acts(f"{p}.mlp.down_proj"), [d_w], "InputsAbsMax", d_w.shape[1]), d_index, d_ref)
+    d_index = d_ref
+    state[f"{p}.self_attn.o_proj.weight"] = o_w[:, o_index]
+    state[f"{p}.self_attn.v_proj.weight"] = state[f"{p}.self_attn.v_proj.weight"][v_proj_order(o_index)]
+    state[f"{p}.mlp.down_proj.weight"] = d_w[:, d_index]
+    for n in ("up_proj", "gate_proj"):
+        state[f"{p}.mlp.{n}.weight"] = state[f"{p}.mlp.{n}.weight"][d_index]
+    for k in want:
+        np.testing.assert_array_equal(state[k], want[k], err_msg=k)
