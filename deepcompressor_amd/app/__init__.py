@@ -6,11 +6,13 @@ from .llm import (ActivationEntry, LinearEntry, LlmActivationQuantizer, LlmActiv
                   LlmWeightQuantizer, LlmWeightQuantizerConfig, load_weight_checkpoint, quantize_layer_activations, quantize_layer_weights,
                   save_weight_checkpoint)
 
-from .llm_stages import LlmQuantConfig, reorder_llm_layer, rotate_llm, smooth_llm_layer
+from .llm_stages import (LlmQuantConfig, quantize_llm_layer_activations, quantize_llm_layer_weights, reorder_llm_layer,
+                         rotate_llm, smooth_llm_layer)
 from .llm_struct import (AttentionConfigStruct, FeedForwardConfigStruct, LlmFeedForwardStruct, LlmModelStruct,
                          LlmSelfAttentionStruct, LlmTransformerBlockStruct, LlmTransformerStruct)
 
-__all__ = ["LlmQuantConfig", "rotate_llm", "reorder_llm_layer", "smooth_llm_layer", "AttentionConfigStruct", "FeedForwardConfigStruct",
+__all__ = ["LlmQuantConfig", "rotate_llm", "reorder_llm_layer", "smooth_llm_layer", "quantize_llm_layer_weights",
+           "quantize_llm_layer_activations", "AttentionConfigStruct", "FeedForwardConfigStruct",
            "LlmFeedForwardStruct", "LlmModelStruct", "LlmSelfAttentionStruct", "LlmTransformerBlockStruct",
            "LlmTransformerStruct", "ActivationEntry", "quantize_layer_activations", "LinearEntry", "LlmActivationQuantizer", "LlmActivationQuantizerConfig", "LlmQuantizer", "LlmQuantizerConfig",
            "LlmWeightQuantizer", "LlmWeightQuantizerConfig", "load_weight_checkpoint", "quantize_layer_weights",

@@ -23,10 +23,13 @@ from ..calib.rotate import (get_rotation_matrix, hadamard_in_channels, rotate_in
 from ..calib.smooth import ActivationSmoother, smooth_attention, smooth_linear_modules
 from ..data.cache import IOTensorsCache
 from ..quantizer.processor import Quantizer
-from .llm import LlmActivationQuantizerConfig, LlmWeightQuantizerConfig
+from ..data.common import TensorType
+from .llm import (ActivationEntry, LinearEntry, LlmActivationQuantizerConfig, LlmWeightQuantizerConfig,
+                  quantize_layer_activations, quantize_layer_weights)
 from .llm_struct import LlmModelStruct, LlmTransformerBlockStruct
 
-__all__ = ["LlmQuantConfig", "rotate_llm", "reorder_llm_layer", "smooth_llm_layer"]
+__all__ = ["LlmQuantConfig", "rotate_llm", "reorder_llm_layer", "smooth_llm_layer", "quantize_llm_layer_weights",
+           "quantize_llm_layer_activations"]
 
 
 @dataclass
@@ -346,3 +349,65 @@ def reorder_llm_layer(layer: LlmTransformerBlockStruct, config: LlmQuantConfig, 
             residual_calibrator.update_channel_metrics(weights=[m.weight for m in up_proj[expert_idx::num_experts]],
                                                        inputs=inputs(ffn.up_proj_names[expert_idx]))
     return residual_calibrator
+
+
+@torch.inference_mode()
+def quantize_llm_layer_weights(layer: LlmTransformerBlockStruct, config: LlmQuantConfig,
+                               quantizer_state_dict: dict[str, tp.Any],
+                               layer_cache: dict[str, IOTensorsCache] | None = None,
+                               layer_kwargs: dict[str, tp.Any] | None = None,
+                               return_with_scale_state_dict: bool = False) -> dict[str, torch.Tensor | float | None]:
+    """The weight stage over a layer struct (app/llm/quant/weight.py:24-105): q_proj / k_proj ranges are scored on
+    their whole attention block, every other linear on itself."""
+    layer_kwargs = layer_kwargs or {}
+    entries = []
+    for key, name, module, parent, field_name in layer.named_key_modules():
+        if field_name in ("q_proj", "k_proj"):
+            entries.append(LinearEntry(key, name, module, eval_name=parent.name, eval_module=parent.module,
+                                       eval_kwargs=parent.filter_kwargs(layer_kwargs)))
+        else:
+            entries.append(LinearEntry(key, name, module))
+    return quantize_layer_weights(entries, config.wgts, quantizer_state_dict, layer_cache=layer_cache,
+                                  return_with_scale_state_dict=return_with_scale_state_dict,
+                                  develop_dtype=config.develop_dtype)
+
+
+@torch.inference_mode()
+def quantize_llm_layer_activations(layer: LlmTransformerBlockStruct, config: LlmQuantConfig,
+                                   quantizer_state_dict: dict[str, tp.Any],
+                                   layer_cache: dict[str, IOTensorsCache] | None = None,
+                                   layer_kwargs: dict[str, tp.Any] | None = None,
+                                   orig_state_dict: dict[str, torch.Tensor] | None = None):
+    """The activation stage over a layer struct (app/llm/quant/activation.py:25-192): the shared input of q/k/v (cached
+    under v_proj, scored on the attention block), the queries / keys / values leaving ``attn.q`` / ``attn.k`` /
+    ``attn.v`` (scored on the attention block), the inputs of the output projection, of the up projections (scored
+    on the feed-forward block) and of every down projection.  Returns ``{cache key: (quantizer, hooks)}``."""
+    layer_kwargs, orig = layer_kwargs or {}, orig_state_dict or {}
+    attn, ffn = layer.attn_struct, layer.ffn_struct
+    attn_kwargs = attn.filter_kwargs(layer_kwargs)
+    In, Out = TensorType.Inputs, TensorType.Outputs
+
+    def originals(names, modules):
+        return [(m.weight, orig[f"{n}.weight"]) for n, m in zip(names, modules, strict=True)] if orig else None
+
+    attn_orig = originals(attn.qkv_proj_names + [attn.out_proj_name], attn.qkv_proj + [attn.out_proj])
+    entries = [ActivationEntry(attn.qkv_proj_key, In, attn.qkv_proj, attn.v_proj_name, attn.module, attn.name,
+                               attn_kwargs, attn_orig)]
+    doubled = (attn_orig + attn_orig) if attn_orig else None
+    for idx, key in enumerate((attn.q_key, attn.k_key, attn.v_key)):
+        module, name = getattr(attn, "qkv"[idx]), getattr(attn, f"{'qkv'[idx]}_name")
+        entries.append(ActivationEntry(key, Out, [module], name, attn.module, attn.name, attn_kwargs,
+                                       doubled[idx:idx + 4] if doubled else None))
+    entries.append(ActivationEntry(attn.out_proj_key, In, [attn.out_proj], attn.out_proj_name, attn.out_proj,
+                                   attn.out_proj_name, None, originals([attn.out_proj_name], [attn.out_proj])))
+    num_experts = ffn.config.num_experts
+    for expert_idx in range(num_experts):
+        ups, up_names = ffn.up_projs[expert_idx::num_experts], ffn.up_proj_names[expert_idx::num_experts]
+        entries.append(ActivationEntry(ffn.up_proj_key, In, ups, up_names[0], ffn.experts[expert_idx], up_names[0], None,
+                                       originals(up_names, ups)))
+        down, down_name = ffn.down_projs[expert_idx], ffn.down_proj_names[expert_idx]
+        entries.append(ActivationEntry(ffn.down_proj_key, In, [down], down_name, down, down_name, None,
+                                       originals([down_name], [down])))
+    return quantize_layer_activations(entries, config.ipts if config.enabled_ipts else None,
+                                      config.opts if config.enabled_opts else None, quantizer_state_dict,
+                                      layer_cache=layer_cache, develop_dtype=config.develop_dtype)

@@ -98,6 +98,14 @@ class LlmSelfAttentionStruct:
         """The layer's keyword arguments that the attention block takes."""
         return {k: v for k, v in kwargs.items() if k in self.kwargs}
 
+    def named_key_modules(self):
+        """(key, name, linear, owner struct, field) of the projections, in the reference's order
+        (nn/struct/attn.py:383-397)."""
+        yield self.qkv_proj_key, self.q_proj_name, self.q_proj, self, "q_proj"
+        yield self.qkv_proj_key, self.k_proj_name, self.k_proj, self, "k_proj"
+        yield self.qkv_proj_key, self.v_proj_name, self.v_proj, self, "v_proj"
+        yield self.out_proj_key, self.o_proj_name, self.o_proj, self, "o_proj"
+
 
 @dataclass
 class LlmFeedForwardStruct:
@@ -128,6 +136,13 @@ class LlmFeedForwardStruct:
         self.up_proj_key, self.down_proj_key = keyed(self.up_proj_rkey), keyed(self.down_proj_rkey)
         self.moe_gate_key = keyed(self.moe_gate_rkey)
 
+    def named_key_modules(self):
+        """nn/struct/attn.py:561-573."""
+        for name, module in zip(self.up_proj_names, self.up_projs, strict=True):
+            yield self.up_proj_key, name, module, self, "up_proj"
+        for name, module in zip(self.down_proj_names, self.down_projs, strict=True):
+            yield self.down_proj_key, name, module, self, "down_proj"
+
 
 @dataclass
 class LlmTransformerBlockStruct:
@@ -147,6 +162,10 @@ class LlmTransformerBlockStruct:
     def __post_init__(self) -> None:
         self.attn_struct.parent = self.ffn_struct.parent = self
         self.attn_structs = [self.attn_struct]
+
+    def named_key_modules(self):
+        yield from self.attn_struct.named_key_modules()
+        yield from self.ffn_struct.named_key_modules()
 
     @classmethod
     def construct(cls, module: nn.Module, name: str) -> "LlmTransformerBlockStruct":

@@ -1630,7 +1630,9 @@ def gen_llm_layer_stages(ref) -> None:
 
     hooks = []
     watched = [(attn.name, attn.module), (attn.q_proj_name, attn.q_proj), (attn.k_proj_name, attn.k_proj),
-               (attn.o_proj_name, attn.o_proj), (ffn.name, ffn.module), (ffn.down_proj_names[0], ffn.down_projs[0])]
+               (attn.o_proj_name, attn.o_proj), (ffn.name, ffn.module), (ffn.down_proj_names[0], ffn.down_projs[0]),
+               (attn.v_proj_name, attn.v_proj), (ffn.up_proj_names[0], ffn.up_projs[0]),
+               (ffn.up_proj_names[1], ffn.up_projs[1])]
     for name, mod in watched:
         hooks += grab(name, mod)
     with torch.no_grad():
@@ -1702,6 +1704,42 @@ def gen_llm_layer_stages(ref) -> None:
             arrays[f"reorder|{tag}|index|{k}"] = v.numpy().copy()
         put_state(f"reorder|{tag}|state", model)
         meta[f"reorder|{tag}"] = dict(indexes=sorted(cache))
+    # weight and activation stages on the smoothed layer (app/llm/quant/weight.py:24-105, activation.py:25-192):
+    # QoQ-style progressive weights (sint8 per channel, then uint4 groups of 16 with integer scales) with a range
+    # search per step; dynamic sint8 inputs per token, uint4 keys / values in groups of 16
+    from deepcompressor.app.llm.quant.activation import quantize_llm_layer_activations
+    from deepcompressor.app.llm.quant.weight import quantize_llm_layer_weights
+    from deepcompressor.calib.config import (
+        SearchBasedCalibGranularity,
+        SearchBasedCalibObjective,
+        SkipBasedDynamicRangeCalibConfig,
+    )
+
+    model.load_state_dict(rotated)
+    cfg = types.SimpleNamespace(wgts=wg, ipts=ip, opts=op, enabled_wgts=True, enabled_ipts=True, enabled_opts=True,
+                                smooth=SmoothTransfomerConfig(proj=plans["manual"][0], attn=plans["manual"][1]),
+                                develop_dtype=torch.float32)
+    smooth_llm_layer(layer, cfg, {}, layer_cache=layer_cache, layer_kwargs=layer_kwargs)
+    calib = SkipBasedDynamicRangeCalibConfig(
+        degree=2, objective=SearchBasedCalibObjective.TensorError, strategy=SearchBasedCalibStrategy.GridSearch,
+        granularity=SearchBasedCalibGranularity.Group, max_shrink=0.4, max_expand=1.0, num_grids=8, skips=[])
+    qoq = LlmWeightQuantizerConfig(dtype=QuantDataType.from_str("uint4"), zero_point=ZeroPointDomain.PostScale,
+                                   group_shapes=((1, -1), (1, 16)), scale_dtypes=(torch.float16, QuantDataType.from_str("sint8")),
+                                   intermediate_dtypes=(QuantDataType.from_str("sint8"),), intermediate_levels=(0,),
+                                   calib_range=calib)
+    cfg.wgts = qoq
+    weight_ranges: dict = {}
+    scale_sd = quantize_llm_layer_weights(layer, cfg, weight_ranges, layer_cache=layer_cache, layer_kwargs=layer_kwargs,
+                                          return_with_scale_state_dict=True)
+    for k, v in scale_sd.items():
+        arrays[f"chain|scale|{k}"] = _np(v if v.ndim else v.view(1))
+    put_state("chain|state", model)
+    act_ranges: dict = {}
+    quantize_llm_layer_activations(layer, cfg, act_ranges, layer_cache=layer_cache, layer_kwargs=layer_kwargs)
+    with torch.no_grad():
+        arrays["logits|chain"] = model(tokens[0]).logits.float().numpy()
+    meta["chain"] = dict(scales=sorted(scale_sd), weight_ranges=sorted(weight_ranges), act_ranges=sorted(act_ranges),
+                         weight_ranges_in_order=list(weight_ranges))
     np.savez_compressed(os.path.join(OUT, "llm_layer_stages.npz"), **arrays)
     with open(os.path.join(OUT, "llm_layer_stages.json"), "w") as f:
         json.dump(meta, f, indent=1)

@@ -172,3 +172,49 @@ def test_manual_reorder_stage_matches_reference():
     reorder_llm_layer(LlmModelStruct.construct(again).backbone_struct.layer_structs[0], config, dict(cache))
     for k, v in host_state(again).items():
         np.testing.assert_array_equal(v, got[k], err_msg=k)
+
+
+def test_weight_and_activation_stages_after_smoothing_match_reference():
+    """The QoQ-style chain's last two stages over the layer struct: progressive weights (sint8 per channel, then
+    uint4 groups of 16 with integer scales and a range search per step) -- every scale.pt entry and every dequantized
+    weight bit-exact -- then dynamic sint8 inputs / uint4 keys and values hooked onto the layer: the logits with every
+    quantizer in place agree with the reference's to bf16 noise."""
+    from deepcompressor_amd.app import quantize_llm_layer_activations, quantize_llm_layer_weights
+    from deepcompressor_amd.calib.config import (SearchBasedCalibGranularity, SearchBasedCalibObjective,
+                                                 SkipBasedDynamicRangeCalibConfig)
+
+    model = build(LS, "smooth|manual|state", "cuda")
+    layer, layer_cache, kwargs = smoothing_inputs(model)
+    config = quant_config(None, None)
+    config.wgts = LlmWeightQuantizerConfig(
+        dtype=QDType.uint4, zero_point=ZeroPointDomain.PostScale, group_shapes=((1, -1), (1, 16)),
+        scale_dtypes=(torch.float16, QDType.sint8), intermediate_dtypes=(QDType.sint8,), intermediate_levels=(0,),
+        calib_range=SkipBasedDynamicRangeCalibConfig(
+            degree=2, objective=SearchBasedCalibObjective.TensorError, strategy=SearchBasedCalibStrategy.GridSearch,
+            granularity=SearchBasedCalibGranularity.Group, max_shrink=0.4, max_expand=1.0, num_grids=8, skips=[]))
+    weight_ranges: dict = {}
+    scale_sd = quantize_llm_layer_weights(layer, config, weight_ranges, layer_cache=layer_cache, layer_kwargs=kwargs,
+                                          return_with_scale_state_dict=True)
+    assert list(weight_ranges) == LS.meta["chain"]["weight_ranges_in_order"]
+    assert sorted(scale_sd) == LS.meta["chain"]["scales"]
+    for k, v in scale_sd.items():
+        assert v.device.type == "cpu"
+        np.testing.assert_array_equal(v.float().numpy().reshape(-1), LS[f"chain|scale|{k}"].reshape(-1), err_msg=k)
+    got, want = host_state(model), values("chain|state")
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    act_ranges: dict = {}
+    hooked = quantize_llm_layer_activations(layer, config, act_ranges, layer_cache=layer_cache, layer_kwargs=kwargs)
+    assert sorted(act_ranges) == LS.meta["chain"]["act_ranges"] == sorted(hooked)
+    tokens = torch.from_numpy(LS["tokens"][0]).cuda()
+    with torch.no_grad():
+        logits = model(tokens).logits.float().cpu().numpy()
+    ref = LS["logits|chain"]
+    assert np.abs(logits - ref).max() <= 0.03 * np.abs(ref).max()
+    # and the quantizers do act: without them the logits sit further from the reference's than with them
+    for _, hooks in hooked.values():
+        for h in hooks:
+            h.remove()
+    with torch.no_grad():
+        plain = model(tokens).logits.float().cpu().numpy()
+    assert np.abs(plain - ref).mean() > np.abs(logits - ref).mean()

@@ -88,7 +88,8 @@ def test_structs_name_modules_like_the_reference():
     struct = LlmModelStruct.construct(build(LS))
     layer = struct.backbone_struct.layer_structs[0]
     attn, ffn = layer.attn_struct, layer.ffn_struct
-    watched = [attn.name, attn.q_proj_name, attn.k_proj_name, attn.o_proj_name, ffn.name, ffn.down_proj_names[0]]
+    watched = [attn.name, attn.q_proj_name, attn.k_proj_name, attn.o_proj_name, ffn.name, ffn.down_proj_names[0],
+               attn.v_proj_name, *ffn.up_proj_names]
     assert watched == LS.meta["watched"]
     assert (attn.qkv_proj_key, attn.out_proj_key, ffn.up_proj_key, ffn.down_proj_key, attn.q_key, attn.k_key) == (
         "qkv_proj", "out_proj", "up_proj", "down_proj", "attn_q", "attn_k")
@@ -97,6 +98,7 @@ def test_structs_name_modules_like_the_reference():
     assert ffn.up_proj_names == ["model.layers.0.mlp.up_proj", "model.layers.0.mlp.gate_proj"]
     assert attn.config.num_query_heads == HEADS and attn.config.num_head_repeats == HEADS // KV
     assert struct.num_head_channels == HC and struct.backbone_struct.num_channels == MODEL["hidden_size"]
+    assert [name for _, name, *_ in layer.named_key_modules()] == LS.meta["chain"]["weight_ranges_in_order"]
 
 
 def v_proj_order(index: np.ndarray) -> np.ndarray:
