@@ -156,6 +156,13 @@ def stage_rates(device, weights, objs) -> dict:
         return e0.elapsed_time(e1) / reps * 1e-3
 
     t_fq = timed(lambda: q.quantize(w), 20)
+    # the same pass on a tensor large enough that one launch outlasts the host's per-call work (~40 us): the kernel's
+    # own streaming rate
+    big = (torch.randn(32768, 8192, device=device, dtype=torch.float32) * 0.02).to(w.dtype)
+    t_big = timed(lambda: q.quantize(big), 10)
+    big_bytes = big.numel() * 4 + (big.numel() // 128) * 8
+    big_shape = list(big.shape)
+    del big
     t_rs = timed(lambda: calibrate_dynamic_range(TensorType.Weights, rcfg, True, q, modules=[None], activations=None,
                                                  weights=[nn.Parameter(w, requires_grad=False)]), 3)
     n = w.numel()
@@ -163,6 +170,9 @@ def stage_rates(device, weights, objs) -> dict:
     return {"fake_quant": {"shape": list(w.shape), "seconds": t_fq, "GBps": fq_bytes / t_fq / 1e9,
                            "frac_of_8TBps": fq_bytes / t_fq / 8e12, "note": "Quantizer.quantize wall time per call "
                            "(one fused kernel + host glue), algorithmic 4.06 B/param"},
+            "fake_quant_streaming": {"shape": big_shape, "seconds": t_big, "GBps": big_bytes / t_big / 1e9,
+                                     "frac_of_8TBps": big_bytes / t_big / 8e12,
+                                     "note": "same call on a 268 M-parameter tensor: launch time dominates host glue"},
             "range_search": {"shape": list(w.shape), "candidates": 101, "seconds": t_rs, "Gparam_per_s": n / t_rs / 1e9,
                              "Gcandidate_evals_per_s": n * 101 / t_rs / 1e9}}
 

@@ -138,7 +138,9 @@ class QuantizerImpl:
         dq, codes, s, z = engine.fake_quant_fused(step, x2d, range_max=rmax, range_min=rmin, ratio=ratio,
                                                   want_dequant=want_dequant, want_codes=want_quant)
         scale = QuantScale().append(s.view(keep))
-        zero = z.view(keep) if sinfo.has_zero_point else torch.tensor(0, dtype=torch.float32, device=tensor.device)
+        zero = None
+        if want_quant:  # (a host-to-device copy when there is no zero point: only when the caller wants it)
+            zero = z.view(keep) if sinfo.has_zero_point else torch.tensor(0, dtype=torch.float32, device=tensor.device)
         quantized = None
         if want_quant:
             if both:
@@ -146,7 +148,7 @@ class QuantizerImpl:
             quantized = restore(codes)
         return QuantTensor(dequantized=restore(dq) if want_dequant else None, quantized=quantized,
                            scale=QuantScale().append(scale) if want_quant else None,
-                           zero=zero if want_quant else None, view_shape=view if want_quant else None)
+                           zero=zero, view_shape=view if want_quant else None)
 
     # ---- general path ------------------------------------------------------------------------
     def _quantize_general(self, tensor, kernel, scale, zero, dynamic_range, round_delta, want_dequant, want_quant,
