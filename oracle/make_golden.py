@@ -1740,6 +1740,22 @@ def gen_llm_layer_stages(ref) -> None:
         arrays["logits|chain"] = model(tokens[0]).logits.float().numpy()
     meta["chain"] = dict(scales=sorted(scale_sd), weight_ranges=sorted(weight_ranges), act_ranges=sorted(act_ranges),
                          weight_ranges_in_order=list(weight_ranges))
+    # the weight stage with the GPTQ kernel on the rotated layer (gptq.yaml's settings, groups of 16): scored in the
+    # tests by codes / layer outputs, not bit for bit (GPTQ is not reproducible across BLAS / LAPACK builds)
+    from deepcompressor.quantizer.kernel.gptq import QuantGptqConfig
+
+    model.load_state_dict(rotated)
+    cfg.wgts = LlmWeightQuantizerConfig(
+        dtype=QuantDataType.from_str("uint4"), zero_point=ZeroPointDomain.PostScale, group_shapes=((1, 16),),
+        scale_dtypes=(torch.float16,), calib_range=calib,
+        kernel_gptq=QuantGptqConfig(damp_percentage=0.01, block_size=128, num_inv_tries=250, hessian_block_size=512))
+    gptq_ranges: dict = {}
+    gptq_scales = quantize_llm_layer_weights(layer, cfg, gptq_ranges, layer_cache=layer_cache, layer_kwargs=layer_kwargs,
+                                             return_with_scale_state_dict=True)
+    for k, v in gptq_scales.items():
+        arrays[f"gptq|scale|{k}"] = _np(v if v.ndim else v.view(1))
+    put_state("gptq|state", model)
+    meta["gptq"] = dict(scales=sorted(gptq_scales))
     np.savez_compressed(os.path.join(OUT, "llm_layer_stages.npz"), **arrays)
     with open(os.path.join(OUT, "llm_layer_stages.json"), "w") as f:
         json.dump(meta, f, indent=1)
