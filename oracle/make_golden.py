@@ -1756,6 +1756,24 @@ def gen_llm_layer_stages(ref) -> None:
         arrays[f"gptq|scale|{k}"] = _np(v if v.ndim else v.view(1))
     put_state("gptq|state", model)
     meta["gptq"] = dict(scales=sorted(gptq_scales))
+    # static per-tensor sint8 inputs with a searched range (smoothquant-static.yaml's kind of setting): every range is
+    # scored on the outputs of the module the reference evaluates it on (attention block, the linear, the mlp)
+    model.load_state_dict(rotated)
+    static_calib = SkipBasedDynamicRangeCalibConfig(
+        degree=2, objective=SearchBasedCalibObjective.OutputsError, strategy=SearchBasedCalibStrategy.GridSearch,
+        granularity=SearchBasedCalibGranularity.Layer, max_shrink=0.4, max_expand=1.0, num_grids=4, skips=[])
+    cfg.ipts = LlmActivationQuantizerConfig(dtype=QuantDataType.from_str("sint8"), zero_point=None,
+                                            group_shapes=((-1, -1),), scale_dtypes=(torch.float16,), static=True,
+                                            calib_range=static_calib)
+    cfg.enabled_opts, cfg.opts = False, LlmActivationQuantizerConfig(dtype=None)
+    static_ranges: dict = {}
+    quantize_llm_layer_activations(layer, cfg, static_ranges, layer_cache=layer_cache, layer_kwargs=layer_kwargs)
+    for k, v in static_ranges.items():
+        (rng,) = v["dynamic_range"]
+        arrays[f"static|max|{k}"] = _np(rng["max"].reshape(-1))
+    with torch.no_grad():
+        arrays["logits|static"] = model(tokens[0]).logits.float().numpy()
+    meta["static"] = dict(ranges=sorted(static_ranges))
     np.savez_compressed(os.path.join(OUT, "llm_layer_stages.npz"), **arrays)
     with open(os.path.join(OUT, "llm_layer_stages.json"), "w") as f:
         json.dump(meta, f, indent=1)

@@ -259,3 +259,34 @@ def test_gptq_weight_stage_on_the_layer_matches_reference():
     print(report)
     for name, (same, out_err) in report.items():
         assert same >= 0.99 and out_err <= 1e-3, report
+
+
+def test_static_activation_ranges_on_the_layer_match_reference():
+    """Static per-tensor sint8 inputs with a range search scored on module outputs (attention block with its keyword
+    arguments, the linears themselves, the mlp): the stored ranges are the reference's.  The candidates' errors are
+    sums over bf16 module outputs, so a search between near-equal candidates could land on the neighbour; the fixture's
+    four searches are not that close."""
+    from deepcompressor_amd.app import quantize_llm_layer_activations
+    from deepcompressor_amd.calib.config import (SearchBasedCalibGranularity, SearchBasedCalibObjective,
+                                                 SkipBasedDynamicRangeCalibConfig)
+
+    model = build(LS, "rotated", "cuda")
+    layer, layer_cache, kwargs = smoothing_inputs(model)
+    config = quant_config(None, None)
+    config.opts = None
+    config.ipts = LlmActivationQuantizerConfig(
+        dtype=QDType.sint8, zero_point=None, group_shapes=((-1, -1),), scale_dtypes=(torch.float16,), static=True,
+        calib_range=SkipBasedDynamicRangeCalibConfig(
+            degree=2, objective=SearchBasedCalibObjective.OutputsError, strategy=SearchBasedCalibStrategy.GridSearch,
+            granularity=SearchBasedCalibGranularity.Layer, max_shrink=0.4, max_expand=1.0, num_grids=4, skips=[]))
+    ranges: dict = {}
+    hooked = quantize_llm_layer_activations(layer, config, ranges, layer_cache=layer_cache, layer_kwargs=kwargs)
+    assert sorted(ranges) == LS.meta["static"]["ranges"] == sorted(hooked)
+    for k, state in ranges.items():
+        (rng,) = state["dynamic_range"]
+        np.testing.assert_array_equal(rng["max"].float().cpu().numpy().reshape(-1), LS[f"static|max|{k}"], err_msg=k)
+    tokens = torch.from_numpy(LS["tokens"][0]).cuda()
+    with torch.no_grad():
+        logits = model(tokens).logits.float().cpu().numpy()
+    ref = LS["logits|static"]
+    assert np.abs(logits - ref).max() <= 0.03 * np.abs(ref).max()
