@@ -89,6 +89,11 @@ def rotate_llm(model: nn.Module | LlmModelStruct, /, config: QuantRotationConfig
     does (rotate.py:25-196).  Returns the rotation matrix."""
     if not hasattr(model, "backbone_struct"):
         model = LlmModelStruct.construct(model)
+    head = model.head if model.backbone_struct.proj_out is None else model.backbone_struct.proj_out
+    assert head is not None, "rotation needs the projection behind the final norm (the language-model head)"
+    if model.backbone_struct.proj_out is None and head.weight is model.backbone_struct.embed_tokens.weight:
+        # the embedding and the head are rotated one after the other: a shared tensor would be rotated twice
+        raise ValueError("rotation of a model with tied input / output embeddings: untie the weights first")
     linears = [m for m in model.module.modules() if isinstance(m, nn.Linear)]
     dtypes = [m.weight.dtype for m in linears]
     for linear in linears:
@@ -119,7 +124,6 @@ def rotate_llm(model: nn.Module | LlmModelStruct, /, config: QuantRotationConfig
                                   next_modules=ffn.up_projs + ([ffn.moe_gate] if ffn.moe_gate is not None else []),
                                   prev_modules=prev_modules, prev_out_channels_dims=prev_dims)
         prev_modules, prev_dims = ffn.down_projs, 0
-    head = model.head if backbone.proj_out is None else backbone.proj_out
     transform_norm_and_linear(parent=backbone.module, norm_name=backbone.norm_out_rname, next_modules=[head],
                               prev_modules=prev_modules, prev_out_channels_dims=prev_dims)
     num_channels = getattr(backbone, "num_channels", None) or backbone.config.num_channels

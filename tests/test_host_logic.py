@@ -138,3 +138,17 @@ def test_llm_stage_config_names_match_reference():
         assert cfg.static is True
         assert cfg.generate_calib_dirname() == m["calib_dirname"], tag
         assert cfg.generate_dirnames(prefix="w") == m["dirnames"], tag
+
+
+def test_rotation_refuses_tied_embeddings():
+    transformers = pytest.importorskip("transformers")
+    from deepcompressor_amd.app import rotate_llm
+    from deepcompressor_amd.calib.config import QuantRotationConfig
+
+    model = transformers.LlamaForCausalLM(transformers.LlamaConfig(
+        vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+        num_key_value_heads=1, tie_word_embeddings=True))
+    dtype = model.lm_head.weight.dtype
+    with pytest.raises(ValueError, match="tied"):
+        rotate_llm(model, QuantRotationConfig())
+    assert model.lm_head.weight.dtype == dtype  # nothing was touched
