@@ -38,10 +38,14 @@ class DynamicRangeCalibrator:
     """Finds the (min, max) per group / channel group / tensor that minimises the quantization error of a tensor."""
 
     def __init__(self, tensor_type: TensorType, config: DynamicRangeCalibConfig, static: bool, quantizer: Quantizer,
-                 pre_scale: torch.Tensor | None = None) -> None:
+                 pre_scale: torch.Tensor | None = None, reduce_errors=None) -> None:
         assert quantizer is not None and quantizer.is_enabled(), "The tensor should be quantized."
         self.tensor_type, self.config, self.static, self.quantizer = tensor_type, config, static, quantizer
         self.pre_scale = pre_scale
+        # rows of the weight sharded over processes: errors that are summed over rows (ChannelGroup / Layer
+        # granularity) are partial here; ``reduce_errors(float64 tensor) -> tensor`` adds them up over the shards
+        # (an all-reduce) before they are rounded and compared, so every shard takes the same decision
+        self.reduce_errors = reduce_errors
         self.develop_dtype = quantizer.develop_dtype
         self.objective, self.granularity = config.objective, config.granularity
         self.ratios = config.get_ratios()
@@ -95,7 +99,10 @@ class DynamicRangeCalibrator:
             return raw.to(dtype)
         dims = [lead + i for i in range(len(self.view_shape[::2]))
                 if not (self.granularity == SearchBasedCalibGranularity.ChannelGroup and i == 1)]
-        return raw.double().sum(dim=dims).view(*raw.shape[:lead], *self.error_shape).to(dtype)
+        total = raw.double().sum(dim=dims)
+        if self.reduce_errors is not None:
+            total = self.reduce_errors(total)
+        return total.view(*raw.shape[:lead], *self.error_shape).to(dtype)
 
     # ---- entry -------------------------------------------------------------------------------------------------
     def _resolve_objective(self, eval_module) -> None:
@@ -297,7 +304,10 @@ class DynamicRangeCalibrator:
             per_group = total.view(CG, R).t()
             if self.granularity == SearchBasedCalibGranularity.Group:
                 return per_group.contiguous()
-            return per_group.double().sum(dim=0).to(torch.float32)  # ChannelGroup
+            total = per_group.double().sum(dim=0)  # ChannelGroup
+            if self.reduce_errors is not None:
+                total = self.reduce_errors(total)
+            return total.to(torch.float32)
 
         return score
 
@@ -590,9 +600,11 @@ def calibrate_dynamic_range(tensor_type: TensorType, config: DynamicRangeCalibCo
                             quantizer: Quantizer, modules: tp.Sequence[nn.Module], activations: TensorsCache,
                             weights: tp.Sequence[nn.Parameter] | None = None, eval_inputs: TensorsCache | None = None,
                             eval_module: nn.Module | None = None, eval_kwargs: dict[str, tp.Any] | None = None,
-                            orig_weights=None, orig_activations=None, orig_eval_inputs=None
+                            orig_weights=None, orig_activations=None, orig_eval_inputs=None, *, reduce_errors=None
                             ) -> tp.Sequence[DynamicRange] | None:
-    """Per-step dynamic ranges of ``quantizer`` (None when nothing has to be stored); calib/range.py:302-474."""
+    """Per-step dynamic ranges of ``quantizer`` (None when nothing has to be stored); calib/range.py:302-474.
+    ``reduce_errors``: for a weight whose rows are sharded over processes, the sum over shards of a float64 tensor of
+    partial errors (see ``deepcompressor_amd.parallel.search_range_row_sharded``)."""
     if config is None or not quantizer.is_enabled():
         return None
     decomposed = quantizer.config.decompose()
@@ -625,7 +637,8 @@ def calibrate_dynamic_range(tensor_type: TensorType, config: DynamicRangeCalibCo
                            orig_y_acts=orig_activations, orig_eval_inputs=orig_eval_inputs)
         x_wgts = []
     if num_steps == 1:
-        calibrator = DynamicRangeCalibrator(tensor_type=tensor_type, config=config, static=static, quantizer=quantizer)
+        calibrator = DynamicRangeCalibrator(tensor_type=tensor_type, config=config, static=static, quantizer=quantizer,
+                                            reduce_errors=reduce_errors)
         return (calibrator.calibrate(x_wgts=x_wgts, **search_args),)
     # progressive quantizer: one calibrator per step, each seeing the tensor divided by the scales found so far
     if tensor_type != TensorType.Weights:
@@ -642,8 +655,8 @@ def calibrate_dynamic_range(tensor_type: TensorType, config: DynamicRangeCalibCo
                                    quant_range=step_info.quant_range, range_bound=step_info.range_bound,
                                    default_dtype=quantizer.default_dtype, develop_dtype=quantizer.develop_dtype)
         step_range = DynamicRangeCalibrator(tensor_type=tensor_type, config=config, static=static,
-                                            quantizer=step_quantizer, pre_scale=quant_scale.data
-                                            ).calibrate(x_wgts=list(weights), **search_args)
+                                            quantizer=step_quantizer, pre_scale=quant_scale.data,
+                                            reduce_errors=reduce_errors).calibrate(x_wgts=list(weights), **search_args)
         dynamic_ranges.append(step_range)
         step_scale, _ = step_info.scale.quantize(tensor=develop_tensor.view(step_info.tensor_shape),
                                                  dynamic_range=step_range)

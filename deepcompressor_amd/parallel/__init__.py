@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 
 __all__ = ["assign_round_robin", "assign_by_cost", "barrier_and_max", "all_reduce_sum", "row_shard", "map_rows_sharded",
-           "run_on_streams"]
+           "search_range_row_sharded", "run_on_streams"]
 
 
 def assign_round_robin(num_items: int, world: int, rank: int) -> list[int]:
@@ -47,9 +47,16 @@ def barrier_and_max(value: float, world: int, device: torch.device | str = "cpu"
 
 
 def all_reduce_sum(t: torch.Tensor, world: int) -> torch.Tensor:
-    """Sum of a small statistics tensor (per-tensor errors, per-channel spans) over ranks, in place."""
+    """Sum of a small statistics tensor (per-tensor errors, per-channel spans) over ranks, in place.  With a backend
+    that has no device path (gloo in the tests) a GPU tensor makes the trip through the host."""
     if world > 1:
-        _dist().all_reduce(t)
+        dist = _dist()
+        if t.is_cuda and dist.get_backend() == "gloo":
+            host = t.cpu()
+            dist.all_reduce(host)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t)
     return t
 
 
@@ -77,6 +84,26 @@ def map_rows_sharded(fn, weight: torch.Tensor, world: int, rank: int, multiple: 
     parts = [torch.empty((e - b, *mine.shape[1:]), dtype=mine.dtype, device=mine.device) for b, e in sizes]
     dist.all_gather(parts, mine) if len({e - b for b, e in sizes}) == 1 else _all_gather_ragged(parts, mine, rank, world)
     return torch.cat(parts, dim=0)
+
+
+def search_range_row_sharded(weight: torch.Tensor, config, quantizer, world: int, rank: int, multiple: int = 1):
+    """Range search of ONE weight whose output rows are split over ``world`` processes (one per GPU).  Every rank
+    searches the slab ``weight[begin:end]``; per-group (Group granularity) decisions need nothing from the others,
+    while errors that are summed over rows (ChannelGroup: one per group of input channels, Layer: one per tensor)
+    are all-reduced -- a table of candidates x channel groups float64 values per candidate batch, the only exchange
+    -- before any rank compares them, so all ranks pick the same candidates.  Returns ``(begin, end, ranges)``, the
+    per-step ranges of the rank's own rows."""
+    import torch.nn as nn
+
+    from ..calib.range import calibrate_dynamic_range
+    from ..data.common import TensorType
+
+    begin, end = row_shard(weight.shape[0], world, rank, multiple)
+    slab = nn.Parameter(weight[begin:end].contiguous(), requires_grad=False)
+    reduce = (lambda t: all_reduce_sum(t, world)) if world > 1 else None
+    ranges = calibrate_dynamic_range(TensorType.Weights, config, True, quantizer, modules=[None], activations=None,
+                                     weights=[slab], reduce_errors=reduce)
+    return begin, end, ranges
 
 
 def _all_gather_ragged(parts: list[torch.Tensor], mine: torch.Tensor, rank: int, world: int) -> None:
