@@ -97,18 +97,29 @@ def clear_hessian_cache() -> None:
         _prepared.clear()
 
 
-def prepare_hessians(caches, device: torch.device) -> list[torch.Tensor]:
+def prepare_hessians(caches, device: torch.device, world: int = 1) -> list[torch.Tensor]:
     """Compute the Hessian of every activation cache in ``caches`` now, one after the other on the current stream
     (each launch has the whole chip), and keep them for ``hessian_of`` calls from any thread until
     ``clear_hessian_cache``.  The pipelines that consume them (inverse factor, sweeps) are latency-bound and may then
-    run concurrently on several streams without slowing the matrix-core SYRKs down."""
+    run concurrently on several streams without slowing the matrix-core SYRKs down.
+
+    ``world`` > 1: the calibration tokens are sharded over the processes of the default group (every rank passes the
+    cache of its own shard).  H is a sum over tokens, so each rank accumulates its shard with the weight 2 / (total
+    number of samples) and the partial Hessians are all-reduced: every rank ends up with the same full H (the same
+    as unsharded up to the order of the float32 sums)."""
+    from ...parallel import all_reduce_sum
+
     out = []
     for inputs in caches:
         key = _inputs_key(inputs, device)
         with _prepared_lock:
             hit = _prepared.get(key)
         if hit is None:
-            hit = _compute_hessian(inputs, device)
+            if world > 1:
+                total = all_reduce_sum(torch.tensor([float(inputs.num_samples)], dtype=torch.float64), world)
+                hit = all_reduce_sum(_compute_hessian(inputs, device, num_samples=int(total.item())), world)
+            else:
+                hit = _compute_hessian(inputs, device)
             with _prepared_lock:
                 _prepared[key] = hit
         out.append(hit)
@@ -147,9 +158,9 @@ def hessian_of(inputs: TensorCache, device: torch.device) -> torch.Tensor:
     return _hessian_cache["value"]
 
 
-def _compute_hessian(inputs: TensorCache, device: torch.device) -> torch.Tensor:
+def _compute_hessian(inputs: TensorCache, device: torch.device, num_samples: int | None = None) -> torch.Tensor:
     hessian = None
-    alpha = 2.0 / inputs.num_samples
+    alpha = 2.0 / (inputs.num_samples if num_samples is None else num_samples)
     for x in inputs.data:
         x2 = inputs.reshape(x.view(-1, *x.shape[inputs.channels_dim:]))
         if hessian is None:

@@ -77,3 +77,59 @@ def test_row_sharded_search_decides_like_the_unsharded_one():
     w = torch.randn(192, 768, generator=g) * 0.02
     w = torch.where(torch.rand(192, 768, generator=g) < 0.01, w * 6, w).to(torch.bfloat16).float()
     assert (plain.reshape(192, 6) < w.view(192, 6, 128).abs().amax(dim=2).numpy()).mean() > 0.2
+
+
+def _gptq_worker(rank: int, world: int, port: int, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        out.put((rank, _gptq(world, rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _gptq(world: int, rank: int):
+    """GPTQ of one 64 x 256 linear on 4 batches of 128 tokens; with two ranks each holds two of the batches."""
+    from deepcompressor_amd.data.cache import TensorCache
+    from deepcompressor_amd.data.dtype import QDType
+    from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
+    from deepcompressor_amd.data.zero import ZeroPointDomain
+    from deepcompressor_amd.quantizer import QuantGptqConfig, Quantizer, QuantizerConfig
+    from deepcompressor_amd.quantizer.kernel import gptq as gm
+
+    g = torch.Generator().manual_seed(21)
+    w = (torch.randn(64, 256, generator=g) * 0.03).to(torch.bfloat16).cuda()
+    gains = torch.exp(torch.randn(256, generator=g) * 0.7)
+    xs = [(torch.randn(1, 128, 256, generator=g) * gains).to(torch.bfloat16).cuda() for _ in range(4)]
+    mine = xs[rank::world]
+    cache = TensorCache(mine, channels_dim=-1, reshape=LinearReshapeFn(), num_cached=len(mine), num_total=len(mine),
+                        num_samples=len(mine), orig_device=torch.device("cuda"))
+    (hessian,) = gm.prepare_hessians([cache], torch.device("cuda", 0), world=world)
+    q = Quantizer(QuantizerConfig(dtype=QDType.uint4, zero_point=ZeroPointDomain.PostScale, group_shapes=((1, 64),),
+                                  scale_dtypes=(torch.float16,)), kernel=QuantGptqConfig(), develop_dtype=torch.float32)
+    out = q.quantize(w, inputs=cache).data
+    gm.clear_hessian_cache()
+    return hessian.cpu().numpy(), out.float().cpu().numpy()
+
+
+def test_token_sharded_hessian_gives_the_unsharded_gptq_result():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gptq_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(out.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    h_whole, w_whole = _gptq(1, 0)
+    (h0, w0), (h1, w1) = results[0], results[1]
+    np.testing.assert_array_equal(h0, h1)  # one all-reduce: both ranks hold the same Hessian
+    np.testing.assert_array_equal(w0, w1)
+    assert np.abs(h0 - h_whole).max() <= 1e-5 * np.abs(h_whole).max()  # float32 sums in another order
+    assert (w0 == w_whole).mean() >= 0.99
