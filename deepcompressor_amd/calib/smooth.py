@@ -162,6 +162,10 @@ class SmoothCalibrator:
         self.w_group_shape, self.x_group_shape, self.y_group_shape = w_gs, x_gs, y_gs
         self.alpha_beta_pairs = config.get_alpha_beta_pairs()
         self.num_iters = 1
+        # calibration tokens sharded over processes: ``reduce_max(t)`` / ``reduce_sum(t)`` return the maximum / sum of
+        # a small tensor over the shards.  Abs-max spans of activations take the maximum (exact: the scales equal the
+        # unsharded ones), every candidate's error the sum, so all shards pick the same candidate.
+        self.reduce_max = self.reduce_sum = None
 
     # ---- candidates
     @property
@@ -192,11 +196,15 @@ class SmoothCalibrator:
             span = span.amax(dim=1, keepdim=True) if use_max else span.mean(dim=1, keepdim=True)
             return span.expand(self.num_heads, 2, -1).reshape(-1)
 
-        def spans_of(tensors, group_shape, modes, *, heads: str, rope: bool):
+        def spans_of(tensors, group_shape, modes, *, heads: str, rope: bool, sharded: bool = True):
             out = {}
             for mode in modes:
                 span = get_smooth_span(tensors, group_shape=group_shape, span_mode=mode, device=device,
                                        dtype=self.develop_dtype)
+                if sharded and self.reduce_max is not None:
+                    if "Max" not in mode.name:
+                        raise NotImplementedError("token-sharded spans are implemented for the AbsMax span only")
+                    span = self.reduce_max(span)
                 if self.num_unique_heads > 0:
                     if heads == "reduce":
                         span = _head_reduce(span, self.num_unique_heads, self.num_head_repeats, "Max" in mode.name)
@@ -214,7 +222,7 @@ class SmoothCalibrator:
         if wgts_centric:
             assert all(w.shape[1] == self.num_in_channels for w in x_wgts)
             w_spans = spans_of([w.data for w in x_wgts], self.w_group_shape, self.config.b_spans, heads="reduce",
-                               rope=False)
+                               rope=False, sharded=False)  # the weights are the same on every shard
             self.span_pairs = [(x_spans[a], w_spans[b]) for a, b in self.config.spans]
         else:
             assert y_acts is not None and y_acts.num_tensors == 1, "Only one output source is allowed"
@@ -467,6 +475,8 @@ class SmoothCalibrator:
                 y = y.pow_(self.config.degree).sum().view(-1)
                 total = y if total is None else total.add_(y)
             self._recover_mod()
+            if self.reduce_sum is not None:
+                total = self.reduce_sum(total)
             self.tell([total])
         return self.get_best()
 
@@ -533,7 +543,7 @@ class SmoothCalibrator:
                         total = total.double().sum(dim=1).to(torch.float32)
                     else:
                         total = total.t().contiguous()
-                errors.append(total)
+                errors.append(total if self.reduce_sum is None else self.reduce_sum(total.contiguous()))
             self.tell(errors)
         return self.get_best()
 
@@ -613,17 +623,24 @@ def smooth_linear_modules(prevs: nn.Module | tp.Sequence[nn.Module] | None, modu
                           eval_inputs: TensorsCache | None = None, eval_module: nn.Module = None,
                           eval_kwargs: dict[str, tp.Any] = None, num_heads: int = 1, num_head_repeats: int = 1,
                           splits: list[int] | None = None, extra_modules: list[nn.Linear] | None = None,
-                          develop_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                          develop_dtype: torch.dtype = torch.float32, world: int = 1) -> torch.Tensor:
     """Find (if ``scale`` is None) and apply the smoothing scale between ``prevs`` and ``modules``: the modules'
     input channels are multiplied, the producers' output channels divided.  Returns the scale on the CPU
-    (smooth.py:919-1015)."""
+    (smooth.py:919-1015).  ``world`` > 1: the cached activations are this rank's shard of the calibration tokens; the
+    activation spans and the candidates' errors are all-reduced over the default process group."""
     modules = list(modules) if isinstance(modules, (list, tuple)) else [modules]
     extra_modules = [] if extra_modules is None else list(extra_modules)
     if scale is None:
         assert inputs is not None or eval_inputs is not None, "inputs or eval_inputs must be provided"
-        scale = SmoothLinearCalibrator(config=config, weight_quantizer=weight_quantizer, input_quantizer=input_quantizer,
-                                       num_heads=num_heads, num_head_repeats=num_head_repeats,
-                                       develop_dtype=develop_dtype).calibrate(
+        calibrator = SmoothLinearCalibrator(config=config, weight_quantizer=weight_quantizer,
+                                            input_quantizer=input_quantizer, num_heads=num_heads,
+                                            num_head_repeats=num_head_repeats, develop_dtype=develop_dtype)
+        if world > 1:
+            from ..parallel import all_reduce_max, all_reduce_sum
+
+            calibrator.reduce_max = lambda t: all_reduce_max(t, world)
+            calibrator.reduce_sum = lambda t: all_reduce_sum(t, world)
+        scale = calibrator.calibrate(
             x_wgts=[m.weight for m in modules] if weights is None else weights, x_acts=inputs, x_mods=modules,
             eval_inputs=eval_inputs, eval_module=eval_module, eval_kwargs=eval_kwargs, splits=splits)
         gc.collect()

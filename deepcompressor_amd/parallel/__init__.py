@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import torch
 
-__all__ = ["assign_round_robin", "assign_by_cost", "barrier_and_max", "all_reduce_sum", "row_shard", "map_rows_sharded",
+__all__ = ["assign_round_robin", "assign_by_cost", "barrier_and_max", "all_reduce_sum", "all_reduce_max", "row_shard", "map_rows_sharded",
            "search_range_row_sharded", "run_on_streams"]
 
 
@@ -46,18 +46,27 @@ def barrier_and_max(value: float, world: int, device: torch.device | str = "cpu"
     return float(t.item())
 
 
-def all_reduce_sum(t: torch.Tensor, world: int) -> torch.Tensor:
-    """Sum of a small statistics tensor (per-tensor errors, per-channel spans) over ranks, in place.  With a backend
-    that has no device path (gloo in the tests) a GPU tensor makes the trip through the host."""
+def _all_reduce(t: torch.Tensor, world: int, op) -> torch.Tensor:
     if world > 1:
         dist = _dist()
         if t.is_cuda and dist.get_backend() == "gloo":
             host = t.cpu()
-            dist.all_reduce(host)
+            dist.all_reduce(host, op=op)
             t.copy_(host)
         else:
-            dist.all_reduce(t)
+            dist.all_reduce(t, op=op)
     return t
+
+
+def all_reduce_sum(t: torch.Tensor, world: int) -> torch.Tensor:
+    """Sum of a small statistics tensor (per-tensor errors, partial Hessians) over ranks, in place.  With a backend
+    that has no device path (gloo in the tests) a GPU tensor makes the trip through the host."""
+    return _all_reduce(t, world, _dist().ReduceOp.SUM) if world > 1 else t
+
+
+def all_reduce_max(t: torch.Tensor, world: int) -> torch.Tensor:
+    """Element-wise maximum over ranks, in place (per-channel abs-max spans of token-sharded activations)."""
+    return _all_reduce(t, world, _dist().ReduceOp.MAX) if world > 1 else t
 
 
 def row_shard(num_rows: int, world: int, rank: int, multiple: int = 1) -> tuple[int, int]:

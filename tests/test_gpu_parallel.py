@@ -133,3 +133,76 @@ def test_token_sharded_hessian_gives_the_unsharded_gptq_result():
     np.testing.assert_array_equal(w0, w1)
     assert np.abs(h0 - h_whole).max() <= 1e-5 * np.abs(h_whole).max()  # float32 sums in another order
     assert (w0 == w_whole).mean() >= 0.99
+
+
+class _Pair(torch.nn.Module):
+    def __init__(self, a, b):
+        super().__init__()
+        self.a, self.b = a, b
+
+    def forward(self, x):
+        return torch.cat([self.a(x), self.b(x)], dim=-1)
+
+
+def _smooth(world: int, rank: int, strategy: str):
+    """Smoothing scale of two linears that share their input, 4 batches of tokens; with two ranks two batches each."""
+    import torch.nn as nn
+
+    from deepcompressor_amd.calib.config import (SearchBasedCalibStrategy, SmoothCalibConfig, SmoothSpanMode)
+    from deepcompressor_amd.calib.smooth import smooth_linear_modules
+    from deepcompressor_amd.data.cache import TensorCache, TensorsCache
+    from deepcompressor_amd.data.dtype import QDType
+    from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
+    from deepcompressor_amd.quantizer import Quantizer, QuantizerConfig
+
+    g = torch.Generator().manual_seed(33)
+    a, b = nn.Linear(64, 40, bias=False, device="cuda"), nn.Linear(64, 24, bias=False, device="cuda")
+    a.weight.data = (torch.randn(40, 64, generator=g) * 0.08).cuda()
+    b.weight.data = (torch.randn(24, 64, generator=g) * 0.08).cuda()
+    gains = torch.exp(torch.randn(64, generator=g) * 1.2)
+    xs = [(torch.randn(2, 12, 64, generator=g) * gains).cuda() for _ in range(4)]
+    mine = xs[rank::world]
+    cache = TensorsCache(TensorCache(mine, channels_dim=-1, reshape=LinearReshapeFn(), num_cached=len(mine),
+                                     num_total=len(mine), num_samples=2 * len(mine), orig_device=torch.device("cuda")))
+    wq = Quantizer(QuantizerConfig(dtype=QDType.sint4, zero_point=None, group_shapes=((1, 16),),
+                                   scale_dtypes=(torch.float16,)), key="w")
+    xq = Quantizer(QuantizerConfig(dtype=QDType.sint8, zero_point=None, group_shapes=((1, -1),),
+                                   scale_dtypes=(torch.float16,)), channels_dim=-1, key="x")
+    manual = strategy == "Manual"
+    cfg = SmoothCalibConfig(spans=[(SmoothSpanMode.AbsMax, SmoothSpanMode.AbsMax)], alpha=0.3 if manual else 0.5,
+                            beta=0.7 if manual else -2, num_grids=10, strategy=SearchBasedCalibStrategy[strategy])
+    scale = smooth_linear_modules(None, [a, b], scale=None, config=cfg, weight_quantizer=wq, input_quantizer=xq,
+                                  inputs=cache, eval_inputs=cache, eval_module=_Pair(a, b), eval_kwargs={}, world=world)
+    return scale.numpy(), a.weight.data.cpu().numpy()
+
+
+def _smooth_worker(rank: int, world: int, port: int, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        out.put((rank, [_smooth(world, rank, s) for s in ("Manual", "GridSearch")]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_token_sharded_smoothing_decides_like_the_unsharded_one():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_smooth_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(out.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i, strategy in enumerate(("Manual", "GridSearch")):
+        scale, weight = _smooth(1, 0, strategy)
+        assert not np.all(scale == 1.0)
+        for r in range(world):  # abs-max spans reduce exactly; the winner of the search is the same
+            np.testing.assert_array_equal(results[r][i][0], scale, err_msg=f"{strategy} rank {r}")
+            np.testing.assert_array_equal(results[r][i][1], weight, err_msg=f"{strategy} rank {r}")

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from deepcompressor_amd.parallel import (all_reduce_sum, assign_by_cost, assign_round_robin, barrier_and_max,
+from deepcompressor_amd.parallel import (all_reduce_max, all_reduce_sum, assign_by_cost, assign_round_robin, barrier_and_max,
                                          map_rows_sharded, row_shard)
 
 
@@ -27,6 +27,9 @@ def _worker(rank: int, world: int, port: int, out):
         elapsed = barrier_and_max(1.0 + rank, world)
         # per-tensor statistics (e.g. layer-granularity errors) are summed over ranks
         stats = all_reduce_sum(torch.tensor([float(len(layers)), float(rank)]), world)
+        # per-channel abs-max spans of token-sharded activations take the maximum over ranks
+        spans = all_reduce_max(torch.tensor([1.0 + rank, 5.0 - rank]), world)
+        assert spans.tolist() == [float(world), 5.0]
         # rows of one linear sharded over ranks: a row-independent operator (stand-in for quantize) gives the same
         # result as unsharded, for even and for ragged splits
         g = torch.Generator().manual_seed(0)
