@@ -1,3 +1,5 @@
+from .linear import ConcatLinear, ShiftedLinear
 from .lowrank import AccumBranchHook, LowRankBranch
+from .sdpa import ScaleDotProductAttention
 
-__all__ = ["LowRankBranch", "AccumBranchHook"]
+__all__ = ["LowRankBranch", "AccumBranchHook", "ConcatLinear", "ShiftedLinear", "ScaleDotProductAttention"]

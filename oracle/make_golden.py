@@ -1779,6 +1779,34 @@ def gen_llm_layer_stages(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+@torch.no_grad()
+def gen_patch_linear(ref) -> None:
+    """The reference's linear patches (nn/patch/linear.py:10-128): a linear split over a concatenated input, and a
+    linear with a shifted input (scalar shift; the per-channel form of the reference's from_linear cannot run)."""
+    import torch.nn as nn
+    from deepcompressor.nn.patch.linear import ConcatLinear, ShiftedLinear
+
+    arrays, meta = {}, {}
+    g = torch.Generator().manual_seed(606)
+    for dt in ("f32", "bf16"):
+        lin = nn.Linear(96, 40, bias=True).to(TORCH_DT[dt])
+        lin.weight.data = (torch.randn(40, 96, generator=g) * 0.1).to(TORCH_DT[dt])
+        lin.bias.data = (torch.randn(40, generator=g) * 0.1).to(TORCH_DT[dt])
+        x = torch.randn(3, 5, 96, generator=g).to(TORCH_DT[dt])
+        arrays[f"{dt}|w"], arrays[f"{dt}|b"], arrays[f"{dt}|x"] = _np(lin.weight.data), _np(lin.bias.data), _np(x)
+        cat = ConcatLinear.from_linear(lin, [32, 16])
+        arrays[f"{dt}|concat|y"] = _np(cat(x))
+        for i, part in enumerate(cat.linears):
+            arrays[f"{dt}|concat|w{i}"] = _np(part.weight.data)
+        meta[f"{dt}|concat"] = dict(widths=cat.in_features_list, bias_on=[p.bias is not None for p in cat.linears])
+        sh = ShiftedLinear.from_linear(lin, 0.17)
+        arrays[f"{dt}|shift|bias"], arrays[f"{dt}|shift|y"] = _np(sh.linear.bias.data), _np(sh(x))
+        arrays[f"{dt}|shift|shift"] = _np(sh.shift)
+    np.savez_compressed(os.path.join(OUT, "patch_linear.npz"), **arrays)
+    with open(os.path.join(OUT, "patch_linear.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 FP_ZERO_CASES = {
     # floating-point types with a zero point: the range is centred on the group mean (data/range.py:323-341)
     "sfp4_post_g32": dict(dtype="sfp4_e2m1_all", zero="PostScale", groups=((1, 32),), sdt=("f16",), shape=(32, 256)),
@@ -1815,7 +1843,7 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "tinychat", "llm_layer_stages"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "tinychat", "llm_layer_stages", "patch_linear"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
