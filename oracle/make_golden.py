@@ -1807,6 +1807,47 @@ def gen_patch_linear(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
+def gen_ste(ref) -> None:
+    """Gradients of the reference's simple_quantize for tensors that require grad (quantizer/impl/simple.py:22-51 with
+    quantizer/impl/ste.py): rounding passes the gradient through, the clamps mask it."""
+    from deepcompressor.data.dtype import QuantDataType
+    from deepcompressor.data.range import QuantRange
+    from deepcompressor.quantizer.impl.simple import simple_quantize
+
+    cases = {
+        "sint4": dict(dtype="sint4", zp=False, amp=4.0),
+        "sint4_zp": dict(dtype="sint4", zp=True, amp=4.0),
+        "uint4_zp": dict(dtype="uint4", zp=True, amp=6.0, shift=7.0),
+        "sint8_range": dict(dtype="sint8", zp=False, amp=80.0, qr=(-119.0, 119.0)),
+        "sfp4": dict(dtype="sfp4_e2m1_all", zp=False, amp=3.5),
+        # (a float type with a quant_range cannot run with grad in the reference: clamp_ on a view made inside
+        # the custom Function is refused by autograd)
+        "sfp8": dict(dtype="sfp8_e4m3_nan", zp=False, amp=300.0),
+        "uexp4": dict(dtype="uexp4_all", zp=False, amp=1.0, positive=True),
+        "f16": dict(dtype="f16", zp=False, amp=2.0),
+        "f16_range": dict(dtype="f16", zp=False, amp=2.0, qr=(-1.5, 2.5)),
+    }
+    arrays, meta = {}, {}
+    g = torch.Generator().manual_seed(707)
+    for name, c in cases.items():
+        x = torch.randn(8, 96, generator=g) * c["amp"] + c.get("shift", 0.0)
+        if c.get("positive"):
+            x = torch.exp(torch.randn(8, 96, generator=g) * 4.0)
+        x[0, :8] = torch.arange(8) - 0.5 if not c.get("positive") else x[0, :8]  # ties and exact bounds
+        up = torch.randn(8, 96, generator=g)
+        leaf = x.clone().requires_grad_(True)
+        qdt = TORCH_DT[c["dtype"]] if c["dtype"] in TORCH_DT else QuantDataType.from_str(c["dtype"])
+        qr = QuantRange(*c["qr"]) if "qr" in c else None
+        out = simple_quantize(leaf * 1.0, quant_dtype=qdt, has_zero_point=c["zp"], quant_range=qr)
+        out.backward(up)
+        arrays[f"{name}|x"], arrays[f"{name}|up"] = _np(x), _np(up)
+        arrays[f"{name}|out"], arrays[f"{name}|grad"] = _np(out.detach()), _np(leaf.grad)
+        meta[name] = {k: v for k, v in c.items()}
+    np.savez_compressed(os.path.join(OUT, "ste.npz"), **arrays)
+    with open(os.path.join(OUT, "ste.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 FP_ZERO_CASES = {
     # floating-point types with a zero point: the range is centred on the group mean (data/range.py:323-341)
     "sfp4_post_g32": dict(dtype="sfp4_e2m1_all", zero="PostScale", groups=((1, 32),), sdt=("f16",), shape=(32, 256)),
@@ -1843,7 +1884,7 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "tinychat", "llm_layer_stages", "patch_linear"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "tinychat", "llm_layer_stages", "patch_linear", "ste"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
