@@ -435,8 +435,8 @@ class SmoothCalibrator:
         if objective == SearchBasedCalibObjective.ProductsError:
             return self._calibrate_products(x_wgts, x_acts or eval_inputs, orig_x_wgts,
                                             kwargs.get("orig_x_acts") or orig_eval_inputs)
-        if objective != SearchBasedCalibObjective.OutputsError:
-            raise NotImplementedError(f"smoothing search with {objective.name} is not implemented")
+        if objective == SearchBasedCalibObjective.TensorError:
+            return self._calibrate_tensor(x_wgts, x_acts or eval_inputs, orig_x_wgts)
         assert eval_inputs is not None, "eval_inputs should not be None when objective is OutputsError"
         assert eval_module is not None, "eval_module should not be None when OutputsError"
         x_acts = x_acts or eval_inputs
@@ -480,6 +480,37 @@ class SmoothCalibrator:
             self.tell([total])
         return self.get_best()
 
+
+    def _calibrate_tensor(self, x_wgts: list[nn.Parameter], x_acts: TensorsCache | None,
+                          orig_x_wgts: list[tuple[nn.Parameter, torch.Tensor]] | None) -> torch.Tensor:
+        """TensorError (search.py:690-696, 776-790): every candidate is scored on the processed weights against the
+        originals, |Q(w s) / s - w|^degree evaluated in the weights' dtype and summed per group of input channels over
+        all rows (ChannelGroup) or over the whole weight (Layer).  The kernel hands back the unrounded float32 sum of
+        every (row, group); they are added up in float64 and rounded to the dtype once, as the reference's one
+        multi-axis ``sum`` rounds once."""
+        assert self.w_quantizer is not None, "TensorError takes the group geometry from the weight quantizer"
+        wgts = [w.detach().data for w in x_wgts]
+        origs = wgts if orig_x_wgts is None else [w for _, w in orig_x_wgts]
+        assert len(origs) == len(wgts)
+        assert all(w.shape[1:] == wgts[0].shape[1:] for w in wgts + origs)
+        views = [infer_view_shape(w.shape, self.w_quantizer.config.largest_group_shape) for w in wgts]
+        refs = [engine.canonical_groups(o.to(device=w.device, dtype=w.dtype), view)[0]
+                for o, w, view in zip(origs, wgts, views)]
+        self.reset(x_wgts=x_wgts, x_acts=x_acts)
+        degree = float(self.config.degree)
+        while not self.is_done():
+            self.ask()
+            errors = []
+            for w, view, ref in zip(wgts, views, refs, strict=True):
+                a2d, _ = engine.canonical_groups(self._process_w_in_xw(w), view)
+                raw = engine.group_error(a2d, ref, degree).view(view[::2]).double()
+                if self.granularity == SearchBasedCalibGranularity.Layer:
+                    total = raw.sum().view(-1)
+                else:  # one error per group of input channels (Group is turned into ChannelGroup by the config)
+                    total = raw.sum(dim=[d for d in range(raw.ndim) if d != 1]).view(view[2])
+                errors.append(total.to(w.dtype))  # (weights are whole on every process: nothing to reduce)
+            self.tell(errors)
+        return self.get_best()
 
     def _calibrate_products(self, x_wgts: list[nn.Parameter], x_acts: TensorsCache | None,
                             orig_x_wgts: list[tuple[nn.Parameter, torch.Tensor]] | None,

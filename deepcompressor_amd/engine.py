@@ -191,6 +191,16 @@ def simple_round_signed(rounding: Rounding, values: torch.Tensor) -> torch.Tenso
     return out.view(values.shape)
 
 
+def assert_finite(values: torch.Tensor, what: str, *, inf_first: bool = False) -> None:
+    """``assert not isnan().any()`` + ``assert not isinf().any()`` of the reference (same messages) as one pass and one
+    host read when everything is finite, which is the case that matters for speed."""
+    if bool(torch.isfinite(values).all()):
+        return
+    checks = [(values.isnan, "NaN"), (values.isinf, "Inf")]
+    for probe, name in (reversed(checks) if inf_first else checks):
+        assert not probe().any(), f"{what} contains {name}."
+
+
 def scale_join(a: torch.Tensor, b: torch.Tensor | None, *, fix_zero: bool) -> torch.Tensor:
     out = torch.empty_like(a)
     check(lib().dcq_scale_join(ptr(a), ptr(b), a.numel(), 1, int(fix_zero), ptr(out), stream_of(a.device)),

@@ -23,6 +23,7 @@ from ...data.zero import ZeroPointDomain
 from ...utils.config import KeyEnableConfig
 from ..config.base import BaseQuantizerConfig
 from ..config.kernel import BaseQuantKernel, BaseQuantKernelConfig
+from ..kernel.gptq import QuantGptqKernel
 from ..kernel.rtn import QuantRtnKernel
 from .info import QuantInfo
 
@@ -207,8 +208,8 @@ class QuantizerImpl:
                                          zero_domain=last.zero_domain, scale=step_scale.data, zero=step_zero,
                                          quant_range=last.quant_range, range_bound=last.range_bound, round_delta=rd,
                                          **kwargs)
-            assert not codes_view.isnan().any(), "Quantized tensor contains NaN."
-            assert not codes_view.isinf().any(), "Quantized tensor contains Inf."
+            if type(kernel) is not QuantGptqKernel:  # (that kernel has made the same check on the same values)
+                engine.assert_finite(codes_view, "Quantized tensor")
             codes, _ = engine.canonical_groups(codes_view.reshape(shape), view)
             if want_dequant:
                 dq = engine.dequantize_groups(step, codes, s, z, outer=outer, deq_clamp=clamp, deq_lo=deq_lo,

@@ -245,8 +245,7 @@ def cholesky_inverse_upper(hessian: torch.Tensor, perm: torch.Tensor | None, dia
                                                ptr(info), stream_of(dev)), "dcq_cholesky_inverse_upper")
         done = int(info.item()) == 0
     assert done, "Hessian could not be factorised"
-    assert not u.isinf().any(), "Inverse of Hessian matrix contains Inf."
-    assert not u.isnan().any(), "Inverse of Hessian matrix contains NaN."
+    engine.assert_finite(u, "Inverse of Hessian matrix", inf_first=True)
     return u, tries
 
 
@@ -317,6 +316,5 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     check(lib().dcq_gptq_sweep(C.byref(step), ptr(W), Cn, R, Cn, ptr(U), ptr(s2), ptr(z2), z_scalar, rg_size, cg_size,
                                n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, stream_of(dev)), "dcq_gptq_sweep")
     Q = Q[:, inverse_perm]
-    assert not Q.isnan().any(), "GPTQ Quantized tensor contains NaN."
-    assert not Q.isinf().any(), "GPTQ Quantized tensor contains Inf."
+    engine.assert_finite(Q, "GPTQ Quantized tensor")
     return Q.reshape(n_rg, rg_size, n_cg, cg_size).contiguous()

@@ -472,7 +472,21 @@ SMOOTH_PRODUCTS_CASES = {
 }
 
 
-def gen_smooth_products(ref) -> None:
+SMOOTH_TENSOR_CASES = {
+    # the same search scored on the weights alone (calib/search.py:690-696, 776-790)
+    "tensor_chgroup": ("TensorError", "ChannelGroup", "f32", 1, 1, False, False),
+    "tensor_chgroup_bf16": ("TensorError", "ChannelGroup", "bf16", 1, 1, False, False),
+    "tensor_chgroup_f16": ("TensorError", "ChannelGroup", "f16", 1, 1, False, False),
+    "tensor_layer": ("TensorError", "Layer", "f32", 1, 1, False, False),
+    "tensor_chgroup_gqa": ("TensorError", "ChannelGroup", "f32", 4, 2, False, False),
+}
+
+
+def gen_smooth_tensor(ref) -> None:
+    gen_smooth_products(ref, SMOOTH_TENSOR_CASES, "smooth_tensor", seed=4343)
+
+
+def gen_smooth_products(ref, cases=None, out_name="smooth_products", seed=4242) -> None:
     """The reference's smoothing search scored on x-w products (calib/search.py:697-745, 791-816) with one winner per
     group of input channels (calib/smooth.py:655-714): every candidate's error tensors and the final scale."""
     import torch.nn as nn
@@ -486,8 +500,8 @@ def gen_smooth_products(ref) -> None:
     from deepcompressor.quantizer.config.base import QuantizerConfig as RefQuantizerConfig
 
     arrays, meta = {}, {}
-    g = torch.Generator().manual_seed(4242)
-    for tag, (objective, granularity, dt, heads, repeats, quant_x, linear_eval) in SMOOTH_PRODUCTS_CASES.items():
+    g = torch.Generator().manual_seed(seed)
+    for tag, (objective, granularity, dt, heads, repeats, quant_x, linear_eval) in (cases or SMOOTH_PRODUCTS_CASES).items():
         dtype = TORCH_DT[dt]
         rows = (40,) if linear_eval else (40, 24)
         mods = [nn.Linear(64, r, bias=False).to(dtype) for r in rows]
@@ -528,8 +542,8 @@ def gen_smooth_products(ref) -> None:
         meta[tag] = dict(objective=objective, granularity=granularity, dtype=dt, num_heads=heads, num_head_repeats=repeats,
                          quantize_inputs=quant_x, linear_eval=linear_eval, rows=list(rows),
                          num_candidates=len(errors))
-    np.savez_compressed(os.path.join(OUT, "smooth_products.npz"), **arrays)
-    with open(os.path.join(OUT, "smooth_products.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, f"{out_name}.npz"), **arrays)
+    with open(os.path.join(OUT, f"{out_name}.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
 
@@ -1884,7 +1898,7 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "tinychat", "llm_layer_stages", "patch_linear", "ste"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "tinychat", "llm_layer_stages", "patch_linear", "ste", "smooth_tensor"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)

@@ -210,13 +210,30 @@ def products_errors(weights, xs, scale, w_spec, x_spec, dt: str, group: int, deg
     return out
 
 
+def tensor_errors(weights, scale, w_spec, dt: str, group: int, degree: float = 2, granularity: str = "ChannelGroup"):
+    """TensorError of one smoothing candidate (search.py:776-790 with the weight processing of smooth.py:504-530): for
+    every linear, |dt(Q(w s) / s) - w|^degree evaluated in the weights' dtype and summed per group of ``group`` input
+    channels over all rows (ChannelGroup) or over the whole weight (Layer)."""
+    s = scale.astype(F32).reshape(-1)
+    out = []
+    for w in weights:
+        ws = (w.astype(F32) * s[None, :]).astype(F32)
+        wq = qo.fake_quantize(ws, "f32", w_spec, default_dtype=dt)["dequant"]
+        wp = qo.round_to(dt, (wq / s[None, :]).astype(F32))
+        e = np.abs(qo.round_to(dt, wp - w.astype(F32)))
+        e = qo.pow_like_torch(e, degree, dt)
+        rows, cols = w.shape
+        out.append(qo._granular_error(e, (rows, 1, cols // group, group), granularity, dt))
+    return out
+
+
 def update_best(best_error, best_scale, error, scale, num_channels: int, num_heads: int = 1, num_head_repeats: int = 1):
     """SmoothCalibrator._update_best (smooth.py:655-714) on lists of per-group error vectors."""
     if best_error is None:
         return [e.copy() for e in error], scale.copy()
     numel = error[0].size
     if numel == 1:
-        if all(float(e) <= float(b) for b, e in zip(best_error, error)):
+        if all(float(e.reshape(-1)[0]) <= float(b.reshape(-1)[0]) for b, e in zip(best_error, error)):
             return [e.copy() for e in error], scale.copy()
         return best_error, best_scale
     group = num_channels // numel
