@@ -22,7 +22,8 @@ def simple_quantize(tensor: torch.Tensor, *, quant_dtype: torch.dtype | QuantDat
             assert not quant_dtype.is_exponent, "round_delta is not supported for exponential quantization"
             assert not quant_dtype.is_float_point, "round_delta is not supported for float quantization"
             qr = QuantRange.construct(quant_dtype, has_zero_point=has_zero_point, quant_range=quant_range)
-            return tensor.floor().add_(round_delta).clamp_(min=qr.min, max=qr.max)
+            floored = _FloorThrough.apply(tensor) if tensor.requires_grad else tensor.floor()
+            return floored.add_(round_delta).clamp_(min=qr.min, max=qr.max)
         out = tensor.to(dtype=quant_dtype).to(dtype=tensor.dtype).add_(round_delta)
         if quant_range is not None and quant_range.is_set():
             out = out.clamp(min=quant_range.min, max=quant_range.max)
@@ -37,6 +38,18 @@ def _snap(tensor: torch.Tensor, quant_dtype, has_zero_point: bool, quant_range: 
                                     device=tensor.device)
     work = tensor.to(torch.float32)
     return engine.simple_round_signed(rounding, work).to(tensor.dtype)
+
+
+class _FloorThrough(torch.autograd.Function):
+    """floor with the identity as its derivative (quantizer/impl/simple.py:49 through quantizer/impl/ste.py:11-27)."""
+
+    @staticmethod
+    def forward(ctx, tensor):
+        return tensor.floor()
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad
 
 
 class _StraightThrough(torch.autograd.Function):

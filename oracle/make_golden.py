@@ -1833,6 +1833,7 @@ def gen_ste(ref) -> None:
         "sint4_zp": dict(dtype="sint4", zp=True, amp=4.0),
         "uint4_zp": dict(dtype="uint4", zp=True, amp=6.0, shift=7.0),
         "sint8_range": dict(dtype="sint8", zp=False, amp=80.0, qr=(-119.0, 119.0)),
+        "sint4_delta": dict(dtype="sint4", zp=True, amp=4.0, delta=True),  # floor + a given 0/1 offset
         "sfp4": dict(dtype="sfp4_e2m1_all", zp=False, amp=3.5),
         # (a float type with a quant_range cannot run with grad in the reference: clamp_ on a view made inside
         # the custom Function is refused by autograd)
@@ -1852,7 +1853,11 @@ def gen_ste(ref) -> None:
         leaf = x.clone().requires_grad_(True)
         qdt = TORCH_DT[c["dtype"]] if c["dtype"] in TORCH_DT else QuantDataType.from_str(c["dtype"])
         qr = QuantRange(*c["qr"]) if "qr" in c else None
-        out = simple_quantize(leaf * 1.0, quant_dtype=qdt, has_zero_point=c["zp"], quant_range=qr)
+        delta = None
+        if c.get("delta"):
+            delta = (torch.rand(8, 96, generator=g) < 0.5).float()
+            arrays[f"{name}|delta"] = _np(delta)
+        out = simple_quantize(leaf * 1.0, quant_dtype=qdt, has_zero_point=c["zp"], quant_range=qr, round_delta=delta)
         out.backward(up)
         arrays[f"{name}|x"], arrays[f"{name}|up"] = _np(x), _np(up)
         arrays[f"{name}|out"], arrays[f"{name}|grad"] = _np(out.detach()), _np(leaf.grad)

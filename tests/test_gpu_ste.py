@@ -16,11 +16,12 @@ ST = load_golden("ste")
 TORCH_DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 
 
-def run(x, up, dtype_name, zp, qr):
+def run(x, up, dtype_name, zp, qr, delta=None):
     qdt = TORCH_DT[dtype_name] if dtype_name in TORCH_DT else QuantDataType.from_str(dtype_name)
     leaf = torch.from_numpy(x).cuda().requires_grad_(True)
     out = simple_quantize(leaf * 1.0, quant_dtype=qdt, has_zero_point=zp,
-                          quant_range=QuantRange(*qr) if qr is not None else None)
+                          quant_range=QuantRange(*qr) if qr is not None else None,
+                          round_delta=torch.from_numpy(delta).cuda() if delta is not None else None)
     out.backward(torch.from_numpy(up).cuda())
     return out.detach().cpu().numpy(), leaf.grad.cpu().numpy()
 
@@ -28,7 +29,8 @@ def run(x, up, dtype_name, zp, qr):
 @pytest.mark.parametrize("name", sorted(ST.meta))
 def test_gradient_matches_reference(name):
     c = ST.meta[name]
-    out, grad = run(ST[f"{name}|x"], ST[f"{name}|up"], c["dtype"], c["zp"], tuple(c["qr"]) if "qr" in c else None)
+    out, grad = run(ST[f"{name}|x"], ST[f"{name}|up"], c["dtype"], c["zp"], tuple(c["qr"]) if "qr" in c else None,
+                    ST[f"{name}|delta"] if c.get("delta") else None)
     assert_bit_equal(out, ST[f"{name}|out"], f"{name} forward")
     if c["dtype"].startswith(("uexp", "sexp")):
         np.testing.assert_allclose(grad, ST[f"{name}|grad"], rtol=5e-7, atol=0)  # mask·q/x then ·upstream against torch's ·q·ln2, /(x·ln2)

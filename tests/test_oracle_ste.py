@@ -19,9 +19,10 @@ def test_oracle_gradient_matches_reference(name):
     c = ST.meta[name]
     qr = tuple(c["qr"]) if "qr" in c else None
     x, up = ST[f"{name}|x"], ST[f"{name}|up"]
-    out = qo.simple_quantize(x, oracle_dtype(c["dtype"]), has_zero_point=c["zp"], qr=qr)
+    delta = ST[f"{name}|delta"] if c.get("delta") else None
+    out = qo.simple_quantize(x, oracle_dtype(c["dtype"]), has_zero_point=c["zp"], qr=qr, round_delta=delta)
     assert_bit_equal(out, ST[f"{name}|out"], f"{name} forward")
-    grad = qo.simple_quantize_grad(x, up, oracle_dtype(c["dtype"]), has_zero_point=c["zp"], qr=qr)
+    grad = qo.simple_quantize_grad(x, up, oracle_dtype(c["dtype"]), has_zero_point=c["zp"], qr=qr, round_delta=delta)
     want = ST[f"{name}|grad"]
     if oracle_dtype(c["dtype"]).__class__ is not str and oracle_dtype(c["dtype"]).is_exponent:
         np.testing.assert_allclose(grad, want, rtol=3e-7, atol=0)  # two float32 roundings (·ln2, /ln2) against torch's
