@@ -1,5 +1,7 @@
+from .conv import ConcatConv2d, ShiftedConv2d
 from .linear import ConcatLinear, ShiftedLinear
 from .lowrank import AccumBranchHook, LowRankBranch
 from .sdpa import ScaleDotProductAttention
 
-__all__ = ["LowRankBranch", "AccumBranchHook", "ConcatLinear", "ShiftedLinear", "ScaleDotProductAttention"]
+__all__ = ["LowRankBranch", "AccumBranchHook", "ConcatLinear", "ShiftedLinear", "ConcatConv2d", "ShiftedConv2d",
+           "ScaleDotProductAttention"]

@@ -1816,6 +1816,28 @@ def gen_patch_linear(ref) -> None:
         sh = ShiftedLinear.from_linear(lin, 0.17)
         arrays[f"{dt}|shift|bias"], arrays[f"{dt}|shift|y"] = _np(sh.linear.bias.data), _np(sh(x))
         arrays[f"{dt}|shift|shift"] = _np(sh.shift)
+    # the convolution counterparts (nn/patch/conv.py:14-182): zero padding, no padding with a per-block shift
+    from deepcompressor.nn.patch.conv import ConcatConv2d, ShiftedConv2d
+    for dt in ("f32", "bf16"):
+        conv = nn.Conv2d(12, 10, 3, stride=1, padding=1, bias=True).to(TORCH_DT[dt])
+        conv.weight.data = (torch.randn(10, 12, 3, 3, generator=g) * 0.1).to(TORCH_DT[dt])
+        conv.bias.data = (torch.randn(10, generator=g) * 0.1).to(TORCH_DT[dt])
+        x = torch.randn(2, 12, 7, 6, generator=g).to(TORCH_DT[dt])
+        arrays[f"{dt}|conv|w"], arrays[f"{dt}|conv|b"], arrays[f"{dt}|conv|x"] = _np(conv.weight.data), _np(conv.bias.data), _np(x)
+        cat = ConcatConv2d.from_conv2d(conv, [4, 5])
+        arrays[f"{dt}|conv|concat|y"] = _np(cat(x))
+        meta[f"{dt}|conv|concat"] = dict(widths=cat.in_channels_list, bias_on=[p.bias is not None for p in cat.convs])
+        sh = ShiftedConv2d.from_conv2d(conv, 0.21)
+        arrays[f"{dt}|conv|shift|bias"], arrays[f"{dt}|conv|shift|y"] = _np(sh.conv.bias.data), _np(sh(x))
+        bare = nn.Conv2d(12, 10, 3, stride=2, padding=0, bias=False).to(TORCH_DT[dt])
+        bare.weight.data = conv.weight.data.clone()
+        block_shift = torch.tensor([0.1, -0.2, 0.3])
+        # (from_conv2d cannot take this: it passes the padding as a tuple, which the constructor compares with 0)
+        sh = ShiftedConv2d(12, 10, 3, shift=block_shift, stride=2, padding=0, bias=True, dtype=TORCH_DT[dt])
+        sh.conv.weight.data.copy_(bare.weight.data)
+        sh.conv.bias.data.zero_()
+        arrays[f"{dt}|conv|blockshift|y"] = _np(sh(x))
+        arrays[f"{dt}|conv|blockshift|shift"] = _np(sh.shift)
     np.savez_compressed(os.path.join(OUT, "patch_linear.npz"), **arrays)
     with open(os.path.join(OUT, "patch_linear.json"), "w") as f:
         json.dump(meta, f, indent=1)
