@@ -34,7 +34,7 @@ from ..utils.config import SkipBasedConfig, configclass
 
 __all__ = ["LlmQuantizerConfig", "LlmWeightQuantizerConfig", "LlmActivationQuantizerConfig", "LlmQuantizer",
            "LlmWeightQuantizer", "LlmActivationQuantizer", "LinearEntry", "ActivationEntry", "quantize_layer_weights",
-           "quantize_layer_activations", "save_weight_checkpoint", "load_weight_checkpoint"]
+           "quantize_layer_activations", "save_weight_checkpoint", "save_checkpoint", "load_checkpoint", "load_weight_checkpoint"]
 
 
 @configclass
@@ -270,26 +270,50 @@ def quantize_layer_activations(entries: tp.Sequence[ActivationEntry], ipts_confi
     return out
 
 
-def save_weight_checkpoint(dirpath: str, *, quantizer_state_dict: dict[str, tp.Any] | None = None,
-                           scale_state_dict: dict[str, tp.Any] | None = None,
-                           model_state_dict: dict[str, torch.Tensor] | None = None) -> dict[str, str]:
-    """Write ``wgts.pt`` / ``scale.pt`` / ``model.pt`` into ``dirpath`` as app/llm/ptq.py:251-266 does; returns the
-    paths written."""
+CHECKPOINT_FILES = ("rotation.pt", "reorder.pt", "smooth.pt", "wgts.pt", "acts.pt", "scale.pt", "model.pt")
+
+
+def save_checkpoint(dirpath: str, *, rotation: torch.Tensor | None = None,
+                    reorder: dict[str, torch.Tensor] | None = None, smooth: dict[str, torch.Tensor] | None = None,
+                    wgts: dict[str, tp.Any] | None = None, acts: dict[str, tp.Any] | None = None,
+                    scale: dict[str, tp.Any] | None = None, model: dict[str, torch.Tensor] | None = None) -> dict[str, str]:
+    """Write the stage results a run of the reference leaves in its cache / save directory (app/llm/ptq.py:74-78,
+    99-103, 121-306), one ``torch.save`` per file: ``rotation.pt`` the rotation matrix; ``reorder.pt`` channel indexes
+    by module name; ``smooth.pt`` smoothing scales by module name; ``wgts.pt`` / ``acts.pt`` the weight / activation
+    quantizers' state dicts by module name; ``scale.pt`` the flattened ``{param}.scale.{level}`` / ``zero`` /
+    ``scaled_zero`` tensors; ``model.pt`` the (fake-quantized) model's state dict.  Returns the paths written."""
     os.makedirs(dirpath, exist_ok=True)
+    parts = dict(rotation=rotation, reorder=reorder, smooth=smooth, wgts=wgts, acts=acts, scale=scale, model=model)
     written = {}
-    for fname, obj in (("wgts.pt", quantizer_state_dict), ("scale.pt", scale_state_dict), ("model.pt", model_state_dict)):
+    for name, obj in parts.items():
         if obj is not None:
-            path = os.path.join(dirpath, fname)
+            path = os.path.join(dirpath, f"{name}.pt")
             torch.save(obj, path)
-            written[fname] = path
+            written[f"{name}.pt"] = path
     return written
 
 
-def load_weight_checkpoint(dirpath: str) -> dict[str, tp.Any]:
-    """Whatever of ``wgts.pt`` / ``scale.pt`` / ``model.pt`` exists in ``dirpath`` (tensor-only files)."""
+def load_checkpoint(dirpath: str) -> dict[str, tp.Any]:
+    """Whatever of the files of ``save_checkpoint`` exists in ``dirpath``, by file name.  The files hold tensors,
+    numbers, None and plain containers only, so they are read with ``weights_only=True``; the rotation matrix comes
+    back in float64, as app/llm/ptq.py:121 converts it."""
     out = {}
-    for fname in ("wgts.pt", "scale.pt", "model.pt"):
+    for fname in CHECKPOINT_FILES:
         path = os.path.join(dirpath, fname)
         if os.path.exists(path):
             out[fname] = torch.load(path, weights_only=True)
+    if "rotation.pt" in out:
+        out["rotation.pt"] = out["rotation.pt"].to(dtype=torch.float64)
     return out
+
+
+def save_weight_checkpoint(dirpath: str, *, quantizer_state_dict: dict[str, tp.Any] | None = None,
+                           scale_state_dict: dict[str, tp.Any] | None = None,
+                           model_state_dict: dict[str, torch.Tensor] | None = None) -> dict[str, str]:
+    """``wgts.pt`` / ``scale.pt`` / ``model.pt`` of the weight stage (app/llm/ptq.py:251-266)."""
+    return save_checkpoint(dirpath, wgts=quantizer_state_dict, scale=scale_state_dict, model=model_state_dict)
+
+
+def load_weight_checkpoint(dirpath: str) -> dict[str, tp.Any]:
+    """Whatever of ``wgts.pt`` / ``scale.pt`` / ``model.pt`` exists in ``dirpath``."""
+    return {k: v for k, v in load_checkpoint(dirpath).items() if k in ("wgts.pt", "scale.pt", "model.pt")}

@@ -152,3 +152,41 @@ def test_rotation_refuses_tied_embeddings():
     with pytest.raises(ValueError, match="tied"):
         rotate_llm(model, QuantRotationConfig())
     assert model.lm_head.weight.dtype == dtype  # nothing was touched
+
+
+def test_stage_checkpoint_files_round_trip(tmp_path):
+    """rotation.pt / reorder.pt / smooth.pt / wgts.pt / acts.pt / scale.pt / model.pt in the reference's shapes
+    (app/llm/ptq.py:74-78, 121-306): written one torch.save per file, read back with tensor-only loading."""
+    import torch
+
+    from deepcompressor_amd.app import load_checkpoint, load_weight_checkpoint, save_checkpoint
+
+    g = torch.Generator().manual_seed(0)
+    parts = dict(
+        rotation=torch.randn(8, 8, generator=g, dtype=torch.float64),
+        reorder={"model.layers.0.self_attn.o_proj": torch.randperm(8, generator=g)},
+        smooth={"model.layers.0.mlp.down_proj": torch.rand(8, generator=g) + 0.5},
+        wgts={"model.layers.0.mlp.up_proj": {"range_bound": None, "dynamic_range": [{"min": None, "max": torch.rand(4, 1, 2, 1, generator=g), "ratio": None}]}},
+        acts={"model.layers.0.mlp.up_proj.input": {"dynamic_range": [{"min": None, "max": torch.rand(1), "ratio": 0.9}]}},
+        scale={"model.layers.0.mlp.up_proj.weight.scale.0": torch.rand(4, 1, 2, 1, generator=g),
+               "model.layers.0.mlp.up_proj.weight.zero": 0},
+        model={"model.layers.0.mlp.up_proj.weight": torch.randn(4, 8, generator=g).to(torch.bfloat16)},
+    )
+    written = save_checkpoint(str(tmp_path), **parts)
+    assert sorted(written) == sorted(f"{k}.pt" for k in parts)
+    back = load_checkpoint(str(tmp_path))
+
+    def same(a, b):
+        if isinstance(a, torch.Tensor):
+            return isinstance(b, torch.Tensor) and a.dtype == b.dtype and torch.equal(a, b)
+        if isinstance(a, dict):
+            return a.keys() == b.keys() and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, list):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return a == b
+
+    for name, obj in parts.items():
+        assert same(obj, back[f"{name}.pt"]), name
+    assert back["rotation.pt"].dtype == torch.float64
+    assert sorted(load_weight_checkpoint(str(tmp_path))) == ["model.pt", "scale.pt", "wgts.pt"]
+    assert save_checkpoint(str(tmp_path / "empty")) == {} and load_checkpoint(str(tmp_path / "empty")) == {}
