@@ -180,7 +180,19 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
     ``quantizer_state_dict`` yet (and stores it there); pass 2 reloads each range, quantizes the weight with the
     configured kernel (GPTQ when set, fed by the linear's cached inputs) and writes the dequantized weight back into
     the module.  Returns the scale state dict when asked for."""
-    layer_cache = layer_cache or {}
+    from ..quantizer.kernel.gptq import clear_hessian_cache
+
+    try:
+        return _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache or {},
+                                       return_with_scale_state_dict, develop_dtype)
+    finally:
+        # the GPTQ kernel memoises the Hessian (and its inverse factor) of the last activation cache together with a
+        # reference to that cache; a layer's caches must not outlive the layer
+        clear_hessian_cache()
+
+
+def _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache, return_with_scale_state_dict,
+                            develop_dtype) -> dict[str, torch.Tensor | float | None]:
     for e in entries:
         assert isinstance(e.module, nn.Linear)
         quantizer = LlmWeightQuantizer(config, develop_dtype=develop_dtype, key=e.key)
@@ -270,38 +282,55 @@ def quantize_layer_activations(entries: tp.Sequence[ActivationEntry], ipts_confi
     return out
 
 
-CHECKPOINT_FILES = ("rotation.pt", "reorder.pt", "smooth.pt", "wgts.pt", "acts.pt", "scale.pt", "model.pt")
+CHECKPOINT_FILES = ("rotation.pt", "reorder.pt", "smooth.pt", "branch.pt", "wgts.pt", "acts.pt", "scale.pt", "model.pt")
 
 
 def save_checkpoint(dirpath: str, *, rotation: torch.Tensor | None = None,
                     reorder: dict[str, torch.Tensor] | None = None, smooth: dict[str, torch.Tensor] | None = None,
                     wgts: dict[str, tp.Any] | None = None, acts: dict[str, tp.Any] | None = None,
-                    scale: dict[str, tp.Any] | None = None, model: dict[str, torch.Tensor] | None = None) -> dict[str, str]:
+                    scale: dict[str, tp.Any] | None = None, model: dict[str, torch.Tensor] | None = None,
+                    branch: dict[str, dict[str, torch.Tensor]] | None = None) -> dict[str, str]:
     """Write the stage results a run of the reference leaves in its cache / save directory (app/llm/ptq.py:74-78,
-    99-103, 121-306), one ``torch.save`` per file: ``rotation.pt`` the rotation matrix; ``reorder.pt`` channel indexes
-    by module name; ``smooth.pt`` smoothing scales by module name; ``wgts.pt`` / ``acts.pt`` the weight / activation
-    quantizers' state dicts by module name; ``scale.pt`` the flattened ``{param}.scale.{level}`` / ``zero`` /
-    ``scaled_zero`` tensors; ``model.pt`` the (fake-quantized) model's state dict.  Returns the paths written."""
+    99-103, 121-306; app/diffusion/ptq.py:205-222 for ``branch.pt``), one ``torch.save`` per file: ``rotation.pt`` the
+    rotation matrix; ``reorder.pt`` channel indexes by module name; ``smooth.pt`` smoothing scales by module name;
+    ``branch.pt`` the low-rank branches' state dicts (``a.weight`` [rank, in], ``b.weight`` [out, rank]) by the name
+    of the first module that shares the branch; ``wgts.pt`` / ``acts.pt`` the weight / activation quantizers' state
+    dicts by module name; ``scale.pt`` the flattened ``{param}.scale.{level}`` / ``zero`` / ``scaled_zero`` tensors;
+    ``model.pt`` the (fake-quantized) model's state dict.  Tensors are written from host memory, so a file never names
+    a GPU of the machine that wrote it.  Returns the paths written."""
     os.makedirs(dirpath, exist_ok=True)
-    parts = dict(rotation=rotation, reorder=reorder, smooth=smooth, wgts=wgts, acts=acts, scale=scale, model=model)
+    parts = dict(rotation=rotation, reorder=reorder, smooth=smooth, branch=branch, wgts=wgts, acts=acts, scale=scale,
+                 model=model)
     written = {}
     for name, obj in parts.items():
         if obj is not None:
             path = os.path.join(dirpath, f"{name}.pt")
-            torch.save(obj, path)
+            torch.save(_to_host(obj), path)
             written[f"{name}.pt"] = path
     return written
 
 
-def load_checkpoint(dirpath: str) -> dict[str, tp.Any]:
+def _to_host(obj):
+    """The same nest of dicts / lists / tuples with every tensor in host memory."""
+    if isinstance(obj, torch.Tensor):
+        return obj.detach().cpu()
+    if isinstance(obj, dict):
+        return type(obj)((k, _to_host(v)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_host(v) for v in obj)
+    return obj
+
+
+def load_checkpoint(dirpath: str, map_location: str | torch.device | None = "cpu") -> dict[str, tp.Any]:
     """Whatever of the files of ``save_checkpoint`` exists in ``dirpath``, by file name.  The files hold tensors,
     numbers, None and plain containers only, so they are read with ``weights_only=True``; the rotation matrix comes
-    back in float64, as app/llm/ptq.py:121 converts it."""
+    back in float64, as app/llm/ptq.py:121 converts it.  ``map_location`` as in ``torch.load`` (host memory unless
+    told otherwise, so files written on another machine load anywhere)."""
     out = {}
     for fname in CHECKPOINT_FILES:
         path = os.path.join(dirpath, fname)
         if os.path.exists(path):
-            out[fname] = torch.load(path, weights_only=True)
+            out[fname] = torch.load(path, weights_only=True, map_location=map_location)
     if "rotation.pt" in out:
         out["rotation.pt"] = out["rotation.pt"].to(dtype=torch.float64)
     return out

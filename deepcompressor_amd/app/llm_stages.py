@@ -165,7 +165,7 @@ def rotate_llm(model: nn.Module | LlmModelStruct, /, config: QuantRotationConfig
     rotate_in_channels((backbone.proj_out if backbone.proj_out is not None else model.head).weight, rotation=rotation)
     for dtype, linear in zip(dtypes, linears, strict=True):
         linear.to(dtype=dtype)
-    return rotation
+    return rotation.cpu()  # as the reference does (rotate.py:196): the matrix is stage output, kept in host memory
 
 
 @torch.inference_mode()

@@ -7,6 +7,7 @@ kernels cannot address directly, and provides the stream.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import torch
 
@@ -255,17 +256,31 @@ def dequantize_groups(step: Step, codes: torch.Tensor, scale, zero, *, outer=Non
     return dq
 
 
-_pow_tables: dict[tuple[torch.device, torch.dtype, float], torch.Tensor] = {}
+_pow_tables: dict[tuple[torch.device, torch.dtype, float], tuple[torch.Tensor, torch.cuda.Event]] = {}
+_pow_tables_lock = threading.Lock()
 
 
 def pow_table(device: torch.device, dtype: torch.dtype, degree: float) -> torch.Tensor:
-    """The 32768-entry table of ``x.pow_(degree)`` over all non-negative bit patterns of a 16-bit dtype."""
+    """The 32768-entry table of ``x.pow_(degree)`` over all non-negative bit patterns of a 16-bit dtype.
+
+    The table is filled by a kernel on the stream of whichever host thread asks first; the cache is shared by all
+    threads (one HIP stream each under ``parallel.run_on_streams``), so every caller's current stream is made to
+    wait for the event recorded behind that kernel before it may launch a consumer."""
     key = (device, dtype, float(degree))
-    if key not in _pow_tables:
-        table = torch.empty(32768, dtype=torch.int16, device=device)
-        check(lib().dcq_pow_table(storage_of(dtype), float(degree), ptr(table), stream_of(device)), "dcq_pow_table")
-        _pow_tables[key] = table
-    return _pow_tables[key]
+    with _pow_tables_lock:
+        entry = _pow_tables.get(key)
+        if entry is None:
+            table = torch.empty(32768, dtype=torch.int16, device=device)
+            stream = torch.cuda.current_stream(device)
+            check(lib().dcq_pow_table(storage_of(dtype), float(degree), ptr(table), stream_of(device)),
+                  "dcq_pow_table")
+            ready = torch.cuda.Event()
+            ready.record(stream)
+            entry = _pow_tables[key] = (table, ready)
+    table, ready = entry
+    if not ready.query():
+        torch.cuda.current_stream(device).wait_event(ready)
+    return table
 
 
 def range_search_groups(step: Step, w: torch.Tensor, ratios: list[float], degree: float, *, want_errors=False,

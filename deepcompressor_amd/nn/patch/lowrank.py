@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-__all__ = ["LowRankBranch", "AccumBranchHook", "leading_singular_triplets"]
+__all__ = ["LowRankBranch", "AccumBranchHook", "leading_singular_triplets", "add_low_rank_branches"]
 
 
 def leading_singular_triplets(weight: torch.Tensor, rank: int) -> tuple[torch.Tensor, torch.Tensor]:
@@ -97,30 +97,31 @@ class LowRankBranch(nn.Module):
 
     @torch.no_grad()
     def reset_parameters(self, weight: torch.Tensor | None = None) -> None:
+        """Without ``weight``: the usual LoRA start (random ``a``, zero ``b``; a zero matrix for the full-rank form).
+        With it: the leading singular triplets of ``weight`` (lowrank.py:30-59 of the reference)."""
+        if self.rank == 0:
+            return
         if weight is None:
-            if self.rank < 0:
-                nn.init.zeros_(self.a.weight)
-            elif self.rank > 0:
+            if self.rank > 0:
                 nn.init.kaiming_uniform_(self.a.weight)
                 nn.init.zeros_(self.b.weight)
+            else:
+                nn.init.zeros_(self.a.weight)
             return
-        if weight.ndim >= 2:
-            assert weight.shape[2:].numel() == 1, "LinearLoRAHook only supports 2D input tensor"
-        weight = weight.view(weight.shape[0], -1)
-        self.to(device=weight.device, dtype=weight.dtype)
-        out_features, in_features = weight.shape
-        assert self.in_features == in_features, "Input features size mismatch"
-        assert self.out_features == out_features, "Output features size mismatch"
+        assert weight.ndim < 2 or weight.shape[2:].numel() == 1, "LinearLoRAHook only supports 2D input tensor"
+        matrix = weight.view(weight.shape[0], -1)
+        assert matrix.shape[1] == self.in_features, "Input features size mismatch"
+        assert matrix.shape[0] == self.out_features, "Output features size mismatch"
+        self.to(device=matrix.device, dtype=matrix.dtype)
         if self.rank < 0:
-            self.a.weight.data.copy_(weight)
-        elif self.rank > 0:
-            us, vh = leading_singular_triplets(weight, self.rank)
-            assert not us.isnan().any(), "NaN in U * S"
-            assert not vh.isnan().any(), "NaN in V^T"
-            assert not us.isinf().any(), "Inf in U * S"
-            assert not vh.isinf().any(), "Inf in V^T"
-            self.a.weight.data.copy_(vh.to(weight.dtype))
-            self.b.weight.data.copy_(us.to(weight.dtype))
+            self.a.weight.data.copy_(matrix)
+            return
+        factors = dict(zip(("U * S", "V^T"), leading_singular_triplets(matrix, self.rank)))
+        for probe, what in ((torch.isnan, "NaN"), (torch.isinf, "Inf")):
+            for name, value in factors.items():
+                assert not probe(value).any(), f"{what} in {name}"
+        self.b.weight.data.copy_(factors["U * S"].to(matrix.dtype))
+        self.a.weight.data.copy_(factors["V^T"].to(matrix.dtype))
 
     def get_effective_weight(self) -> torch.Tensor | None:
         if self.rank == 0:
@@ -143,3 +144,36 @@ class LowRankBranch(nn.Module):
 
     def as_hook(self, input_packager=None, output_packager=None) -> AccumBranchHook:
         return AccumBranchHook(self, input_packager=input_packager, output_packager=output_packager)
+
+
+@torch.no_grad()
+def add_low_rank_branches(modules: list[nn.Module], state_dict: dict[str, torch.Tensor], rank: int) -> list[LowRankBranch]:
+    """Put one stored entry of ``branch.pt`` to work (reference: app/diffusion/quant/weight.py:117-144).
+
+    ``state_dict`` holds ``a.weight`` [rank, in] and ``b.weight`` [sum of the modules' output features, rank] of the
+    branch calibrated for ``modules`` together (modules that share their input, e.g. q / k / v, share ``a``).  Every
+    module gets a branch with the shared ``a`` and its own rows of ``b``; the branch's effective weight is taken out
+    of the module's weight, and the branch is hooked behind the module so that the sum of both is unchanged.
+    Returns the branches in module order."""
+    first = modules[0].weight
+    in_features = first.shape[1]
+    shared = LowRankBranch(in_features=in_features, out_features=sum(m.weight.shape[0] for m in modules), rank=rank)
+    shared.to(device=first.device, dtype=first.dtype)
+    shared.load_state_dict(state_dict)
+    if len(modules) == 1:
+        first.data.sub_(shared.get_effective_weight().view(first.shape))
+        shared.as_hook().register(modules[0])
+        return [shared]
+    branches, row = [], 0
+    for module in modules:
+        weight = module.weight
+        rows = weight.shape[0]
+        branch = LowRankBranch(in_features=in_features, out_features=rows, rank=rank)
+        branch.a = shared.a
+        branch.b.to(device=weight.device, dtype=weight.dtype)
+        branch.b.weight.copy_(shared.b.weight[row:row + rows])
+        row += rows
+        weight.data.sub_(branch.get_effective_weight().view(weight.shape))
+        branch.as_hook().register(module)
+        branches.append(branch)
+    return branches

@@ -35,12 +35,25 @@ def _dist():
     return dist
 
 
-def barrier_and_max(value: float, world: int, device: torch.device | str = "cpu") -> float:
-    """Barrier, then the maximum of ``value`` over all ranks (identity for one rank)."""
+def _collective_device(dist) -> torch.device:
+    """Where a tensor must live for the default group's backend: RCCL ("nccl") only moves accelerator memory,
+    gloo only host memory."""
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def barrier_and_max(value: float, world: int, device: torch.device | str | None = None) -> float:
+    """Barrier, then the maximum of ``value`` over all ranks (identity for one rank).  ``device`` defaults to the
+    one the backend can move (the current GPU under RCCL, the host under gloo)."""
     if world <= 1:
         return value
     dist = _dist()
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    home = _collective_device(dist)
+    dev = home if device is None else torch.device(device)
+    if dev.type != home.type:
+        dev = home
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.barrier()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -49,10 +62,11 @@ def barrier_and_max(value: float, world: int, device: torch.device | str = "cpu"
 def _all_reduce(t: torch.Tensor, world: int, op) -> torch.Tensor:
     if world > 1:
         dist = _dist()
-        if t.is_cuda and dist.get_backend() == "gloo":
-            host = t.cpu()
-            dist.all_reduce(host, op=op)
-            t.copy_(host)
+        home = _collective_device(dist)
+        if t.device.type != home.type:  # GPU tensor on gloo, or host tensor on RCCL: make the trip, copy back
+            moved = t.to(home)
+            dist.all_reduce(moved, op=op)
+            t.copy_(moved)
         else:
             dist.all_reduce(t, op=op)
     return t

@@ -72,26 +72,27 @@ class _State(threading.local):
 
     workspaces: one scratch buffer per device.
     hessian: the weights fed by the same activations (q/k/v, gate/up) share one Hessian -- the most recent one is
-    kept, keyed by the identity of the cached activation tensors.
+    kept, keyed by the identity of the cached activation tensors, which the memo holds by reference: a freed
+    cache whose address the allocator hands to the next layer's cache can therefore never match.
     factor: ... and therefore one act-order permutation and one inverse factor, kept for the most recent Hessian
     tensor (held by reference, so its storage cannot be recycled under the key)."""
 
     def __init__(self):
         self.workspaces: dict[torch.device, torch.Tensor] = {}
-        self.hessian: dict = {"key": None, "value": None}
+        self.hessian: dict = {"key": None, "refs": None, "value": None}
         self.factor: dict = {"key": None, "value": None}
 
 
 _state = _State()
 # Hessians computed ahead of time by ``prepare_hessians`` (any number, visible to every host thread) until
 # ``clear_hessian_cache``; read-only once stored.
-_prepared: dict = {}
+_prepared: dict = {}  # key -> (activation tensors held alive, Hessian)
 _prepared_lock = threading.Lock()
 
 
 def clear_hessian_cache() -> None:
     """Drop this thread's memoised Hessian and inverse factor, and every prepared Hessian."""
-    _state.hessian["key"] = _state.hessian["value"] = None
+    _state.hessian["key"] = _state.hessian["refs"] = _state.hessian["value"] = None
     _state.factor["key"] = _state.factor["value"] = None
     with _prepared_lock:
         _prepared.clear()
@@ -112,18 +113,31 @@ def prepare_hessians(caches, device: torch.device, world: int = 1) -> list[torch
     out = []
     for inputs in caches:
         key = _inputs_key(inputs, device)
-        with _prepared_lock:
-            hit = _prepared.get(key)
+        hit = _prepared_lookup(key, inputs)
         if hit is None:
             if world > 1:
-                total = all_reduce_sum(torch.tensor([float(inputs.num_samples)], dtype=torch.float64), world)
+                # on the accelerator: the RCCL backend has no path for host tensors
+                total = all_reduce_sum(torch.tensor([float(inputs.num_samples)], dtype=torch.float64, device=device),
+                                       world)
                 hit = all_reduce_sum(_compute_hessian(inputs, device, num_samples=int(total.item())), world)
             else:
                 hit = _compute_hessian(inputs, device)
             with _prepared_lock:
-                _prepared[key] = hit
+                _prepared[key] = (tuple(inputs.data), hit)
         out.append(hit)
     return out
+
+
+def _same_tensors(refs, inputs: TensorCache) -> bool:
+    return refs is not None and len(refs) == len(inputs.data) and all(a is b for a, b in zip(refs, inputs.data))
+
+
+def _prepared_lookup(key, inputs: TensorCache):
+    with _prepared_lock:
+        entry = _prepared.get(key)
+    if entry is not None and _same_tensors(entry[0], inputs):
+        return entry[1]
+    return None
 
 
 def cached_hessian_key():
@@ -140,21 +154,25 @@ def _version_of(t: torch.Tensor) -> int:
 
 
 def _inputs_key(inputs: TensorCache, device: torch.device):
+    """Hashable part of a cache's identity.  ``id`` / ``data_ptr`` only mean something while the tensor objects are
+    alive, so every memo keeps the tensors themselves next to this key and compares them with ``is``
+    (``_same_tensors``).  The in-place counter catches edits made outside ``torch.inference_mode``; tensors created
+    under it carry no counter -- after editing such a cache in place call ``clear_hessian_cache``."""
     return (device, inputs.num_samples, inputs.channels_dim,
-            tuple((t.data_ptr(), tuple(t.shape), t.dtype, _version_of(t)) for t in inputs.data))
+            tuple((id(t), t.data_ptr(), tuple(t.shape), t.dtype, _version_of(t)) for t in inputs.data))
 
 
 def hessian_of(inputs: TensorCache, device: torch.device) -> torch.Tensor:
     """2 / num_samples * sum_x x^T x over the cache (float32, C x C), memoised for the last cache seen."""
     key = _inputs_key(inputs, device)
-    with _prepared_lock:
-        hit = _prepared.get(key)
+    hit = _prepared_lookup(key, inputs)
     if hit is not None:
         return hit
     _hessian_cache = _state.hessian
-    if _hessian_cache["key"] != key:
-        _hessian_cache["key"] = _hessian_cache["value"] = None
-        _hessian_cache["key"], _hessian_cache["value"] = key, _compute_hessian(inputs, device)
+    if _hessian_cache["key"] != key or not _same_tensors(_hessian_cache["refs"], inputs):
+        _hessian_cache["key"] = _hessian_cache["refs"] = _hessian_cache["value"] = None
+        value = _compute_hessian(inputs, device)
+        _hessian_cache["key"], _hessian_cache["refs"], _hessian_cache["value"] = key, tuple(inputs.data), value
     return _hessian_cache["value"]
 
 

@@ -629,6 +629,61 @@ def gen_lowrank(ref) -> None:
     with open(os.path.join(OUT, "lowrank.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
+@torch.no_grad()
+def gen_branch(ref) -> None:
+    """``branch.pt`` contents: the state dicts of the reference's LowRankBranch modules as
+    app/diffusion/quant/weight.py:107-116 stores them, and what lines 117-144 of that file do with a stored entry
+    (shared ``a``, ``b`` split over the modules that share their input, the effective weight subtracted from each
+    module, the branch hooked behind it) -- run here with the reference's own LowRankBranch / AccumBranchHook."""
+    import torch.nn as nn
+    from deepcompressor.nn.patch.lowrank import LowRankBranch
+
+    arrays, meta = {}, {}
+    g = torch.Generator().manual_seed(77)
+    rank = 4
+    for tag, dt, outs in (("qkv_bf16", "bf16", (40, 24, 24)), ("single_f32", "f32", (48,)), ("pair_f16", "f16", (32, 16))):
+        dtype = TORCH_DT[dt]
+        mods = [nn.Linear(64, o, bias=False) for o in outs]
+        for m in mods:
+            m.weight.data = (torch.randn(m.weight.shape, generator=g) * 0.05
+                             + torch.randn(m.weight.shape[0], 3, generator=g) @ torch.randn(3, 64, generator=g) * 0.1)
+            m.to(dtype)
+        x = torch.randn(6, 64, generator=g).to(dtype)
+        for i, m in enumerate(mods):
+            arrays[f"{tag}|w{i}"] = _np(m.weight.data).copy()  # (float32: .numpy() shares the tensor's memory)
+        arrays[f"{tag}|x"] = _np(x).copy()
+        joint = torch.cat([m.weight.data for m in mods], dim=0)
+        state = LowRankBranch(64, joint.shape[0], rank=rank, weight=joint).state_dict()
+        assert sorted(state) == ["a.weight", "b.weight"]
+        for k, v in state.items():
+            arrays[f"{tag}|state|{k}"] = _np(v).copy()
+        # app/diffusion/quant/weight.py:117-144
+        shared = LowRankBranch(in_features=64, out_features=joint.shape[0], rank=rank)
+        shared.to(dtype=dtype)
+        shared.load_state_dict(state)
+        if len(mods) > 1:
+            oc = 0
+            for m in mods:
+                branch = LowRankBranch(in_features=64, out_features=m.weight.shape[0], rank=rank)
+                branch.a = shared.a
+                branch.b.to(dtype=dtype)
+                branch.b.weight.copy_(shared.b.weight[oc:oc + m.weight.shape[0]])
+                oc += m.weight.shape[0]
+                m.weight.data.sub_(branch.get_effective_weight().view(m.weight.data.shape))
+                branch.as_hook().register(m)
+        else:
+            mods[0].weight.data.sub_(shared.get_effective_weight().view(mods[0].weight.data.shape))
+            shared.as_hook().register(mods[0])
+        for i, m in enumerate(mods):
+            arrays[f"{tag}|after{i}"] = _np(m.weight.data).copy()
+            arrays[f"{tag}|y{i}"] = _np(m(x)).copy()
+        meta[tag] = dict(dtype=dt, outs=list(outs), rank=rank, in_features=64,
+                         state_dtypes={k: str(v.dtype) for k, v in state.items()})
+    np.savez_compressed(os.path.join(OUT, "branch.npz"), **arrays)
+    with open(os.path.join(OUT, "branch.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 RANGE_WIDE_EXTRA_CASES = {
     # groups longer than 512 values: per-channel rows of 2048
     "sint4_gchn_long": dict(dtype="sint4", zero=None, groups=((1, -1),), sdt=("f16",), shape=(16, 2048)),
@@ -1925,7 +1980,7 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "tinychat", "llm_layer_stages", "patch_linear", "ste", "smooth_tensor"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "tinychat", "llm_layer_stages", "patch_linear", "ste", "smooth_tensor", "branch"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)

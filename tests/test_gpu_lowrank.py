@@ -119,3 +119,50 @@ def test_leading_triplets_match_full_svd_at_model_size(shape):
     branch = LowRankBranch(in_f, out_f, 32, weight=w)
     eff = branch.get_effective_weight()
     assert eff.dtype == w.dtype and (eff.double() - us @ vh).abs().max() < 2e-2 * float(sigma[0]) / 32
+
+
+BR = load_golden("branch")
+
+
+@pytest.mark.parametrize("tag", sorted(BR.meta))
+def test_branch_checkpoint_round_trip(tag, tmp_path):
+    """``branch.pt``: the reference's stored branch (its LowRankBranch.state_dict() for modules that share an input)
+    written and read back by the checkpoint writer, then put to work: the shared ``a``, each module's rows of ``b``,
+    the effective weight taken out of each module and the hooked outputs, against what the reference's own code
+    produced from the same entry; and this package's branch for the same weights has the same keys, shapes, dtypes
+    and (up to the sign freedom of singular vectors) the same product."""
+    from deepcompressor_amd.app import load_checkpoint, save_checkpoint
+    from deepcompressor_amd.nn.patch import add_low_rank_branches
+
+    m = BR.meta[tag]
+    dt, rank = m["dtype"], m["rank"]
+    state = {k: to_device(BR[f"{tag}|state|{k}"], dt) for k in ("a.weight", "b.weight")}
+    written = save_checkpoint(str(tmp_path), branch={"blocks.0.attn.to_q": state})
+    assert list(written) == ["branch.pt"]
+    back = load_checkpoint(str(tmp_path))["branch.pt"]["blocks.0.attn.to_q"]
+    assert sorted(back) == ["a.weight", "b.weight"] and all(v.device.type == "cpu" for v in back.values())
+    for k in state:
+        assert back[k].dtype == state[k].dtype and torch.equal(back[k], state[k].cpu())
+    mods = []
+    for i, rows in enumerate(m["outs"]):
+        lin = nn.Linear(m["in_features"], rows, bias=False, device="cuda", dtype=state["a.weight"].dtype)
+        lin.weight.data = to_device(BR[f"{tag}|w{i}"], dt)
+        mods.append(lin)
+    joint = torch.cat([lin.weight.data for lin in mods], dim=0)
+    branches = add_low_rank_branches(mods, back, rank)
+    assert len(branches) == len(mods) and all(b.a is branches[0].a for b in branches)
+    x = to_device(BR[f"{tag}|x"], dt)
+    step = {"f32": 2e-6, "bf16": 2.0 ** -8, "f16": 2.0 ** -10}[dt]  # one rounding of the weight dtype
+    for i, lin in enumerate(mods):
+        want = BR[f"{tag}|after{i}"]
+        assert np.abs(to_np(lin.weight.data) - want).max() <= step * np.abs(BR[f"{tag}|w{i}"]).max()
+        want_y = BR[f"{tag}|y{i}"]
+        assert np.abs(to_np(lin(x)) - want_y).max() <= 4 * step * np.abs(want_y).max()
+    # this package's own branch for the same joint weight
+    own = LowRankBranch(m["in_features"], joint.shape[0], rank=rank, weight=joint).state_dict()
+    assert sorted(own) == sorted(state)
+    for k in state:
+        assert own[k].shape == state[k].shape and own[k].dtype == state[k].dtype
+    eff_ref = (state["b.weight"].double() @ state["a.weight"].double())
+    eff_own = (own["b.weight"].double() @ own["a.weight"].double())
+    assert (eff_own - eff_ref).abs().max() <= 4 * step * joint.abs().max()

@@ -155,8 +155,8 @@ def test_rotation_refuses_tied_embeddings():
 
 
 def test_stage_checkpoint_files_round_trip(tmp_path):
-    """rotation.pt / reorder.pt / smooth.pt / wgts.pt / acts.pt / scale.pt / model.pt in the reference's shapes
-    (app/llm/ptq.py:74-78, 121-306): written one torch.save per file, read back with tensor-only loading."""
+    """rotation.pt / reorder.pt / smooth.pt / branch.pt / wgts.pt / acts.pt / scale.pt / model.pt in the reference's
+    shapes (app/llm/ptq.py:74-78, 121-306; app/diffusion/ptq.py:205-222): written one torch.save per file, read back with tensor-only loading."""
     import torch
 
     from deepcompressor_amd.app import load_checkpoint, load_weight_checkpoint, save_checkpoint
@@ -171,6 +171,8 @@ def test_stage_checkpoint_files_round_trip(tmp_path):
         scale={"model.layers.0.mlp.up_proj.weight.scale.0": torch.rand(4, 1, 2, 1, generator=g),
                "model.layers.0.mlp.up_proj.weight.zero": 0},
         model={"model.layers.0.mlp.up_proj.weight": torch.randn(4, 8, generator=g).to(torch.bfloat16)},
+        branch={"transformer_blocks.0.attn.to_q": {"a.weight": torch.randn(2, 8, generator=g).to(torch.bfloat16),
+                                                   "b.weight": torch.randn(12, 2, generator=g).to(torch.bfloat16)}},
     )
     written = save_checkpoint(str(tmp_path), **parts)
     assert sorted(written) == sorted(f"{k}.pt" for k in parts)
