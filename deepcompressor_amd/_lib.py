@@ -78,6 +78,7 @@ _SIGNATURES = {
     "dcq_pack_tinychat_w4": [_p, _i64, _i64, _p, _p],
     "dcq_gemm_f32": [_p, _i64, _i32, _p, _i64, _p, _i64, _i64, _i64, _i64, _f, _f, _p],
     "dcq_cholesky_inverse_upper": [_p, _i64, _p, _f, _p, _p, _i64, _p, _p],
+    "dcq_cholesky_inverse_upper_static": [_p, _i64, _p, _f, _p, _p, _p],
     "dcq_gemm_f64": [_p, _i32, _i64, _i32, _i64, _p, _i32, _i64, _i64, _p, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "dcq_channel_metric": [_p, _i32, _i64, _i64, _i64, _i32, _p, _p, _p],
     "dcq_scale_channels": [_p, _i32, _i64, _i64, _i64, _p, _i64, _i32, _p, _i32, _p],

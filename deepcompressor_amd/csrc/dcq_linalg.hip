@@ -13,6 +13,8 @@
 // rows R[k][:] are at once the A operand (transposed) and the B operand of the trailing update.
 #include "dcq_common.cuh"
 
+#include <mutex>
+
 namespace dcq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -488,6 +490,42 @@ static int factor_invert(float* A, float* X, float* T, int64_t np, int lo, int h
   return DCQ_OK;
 }
 
+int cholesky_inverse_upper_on(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U, void* workspace,
+                              int32_t* info, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Built-in scratch for dcq_cholesky_inverse_upper_static: callers that may not allocate (HIP graph capture, serving
+// loops) get the factorisation's workspace from this file-scope device array instead of an argument.  Every GPU the
+// library runs on holds its own copy at its own address; `scratch` itself is only the host-side handle of the
+// symbol, so the address is looked up once per device (hipGetSymbolAddress with that device current) and only that
+// pointer is ever handed to kernels and memsets.
+// ---------------------------------------------------------------------------------------------
+constexpr int kStaticCholMaxN = 2048;
+constexpr size_t kStaticCholBytes = 2ull * kStaticCholMaxN * kStaticCholMaxN * 4 + 1ull * (kStaticCholMaxN / 2) * (kStaticCholMaxN / 2) * 4;
+static __device__ __align__(256) unsigned char scratch[kStaticCholBytes];  // 36 MiB per GPU, for the process's lifetime
+
+constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mutex;
+
+static int static_scratch_of_current_device(void** out) {
+  int dev = 0;
+  int rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
+  if (rc != DCQ_OK) return rc;
+  DCQ_REQUIRE(dev >= 0 && dev < kMaxDevices, DCQ_ERR_UNSUPPORTED, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> guard(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* ptr = nullptr;
+    rc = hip_check(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)");
+    if (rc != DCQ_OK) return rc;
+    DCQ_REQUIRE(ptr != nullptr && (reinterpret_cast<uintptr_t>(ptr) & 255u) == 0, DCQ_ERR_HIP,
+                "scratch symbol resolved to a bad address");
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return DCQ_OK;
+}
+
 }  // namespace dcq
 
 using namespace dcq;
@@ -528,8 +566,30 @@ int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, f
   DCQ_REQUIRE(H && U && workspace && info, DCQ_ERR_ARGUMENT, "NULL buffer");
   DCQ_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, DCQ_ERR_ARGUMENT, "workspace must be 256-byte aligned");
   DCQ_REQUIRE(workspace_bytes >= dcq_cholesky_workspace_bytes(n), DCQ_ERR_ARGUMENT, "workspace too small");
+  return cholesky_inverse_upper_on(H, n, perm, diag_add, U, workspace, info, static_cast<hipStream_t>(stream));
+}
+
+int dcq_cholesky_inverse_upper_static(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U,
+                                      int32_t* info, dcq_stream_t stream) {
+  DCQ_REQUIRE(n > 0, DCQ_ERR_ARGUMENT, "bad n");
+  DCQ_REQUIRE(n <= kStaticCholMaxN, DCQ_ERR_UNSUPPORTED,
+              "n = %lld exceeds the built-in scratch of dcq_cholesky_inverse_upper_static (n <= %d); use "
+              "dcq_cholesky_inverse_upper with a caller-provided workspace",
+              (long long)n, kStaticCholMaxN);
+  DCQ_REQUIRE(H && U && info, DCQ_ERR_ARGUMENT, "NULL buffer");
+  void* ws = nullptr;
+  const int rc = static_scratch_of_current_device(&ws);
+  if (rc != DCQ_OK) return rc;
+  return cholesky_inverse_upper_on(H, n, perm, diag_add, U, ws, info, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
+
+namespace dcq {
+
+int cholesky_inverse_upper_on(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U, void* workspace,
+                              int32_t* info, hipStream_t s) {
   const CholPlan c = plan_chol(n);
-  hipStream_t s = static_cast<hipStream_t>(stream);
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   float* A = reinterpret_cast<float*>(ws);
   float* X = reinterpret_cast<float*>(ws + c.a_bytes);
@@ -552,4 +612,4 @@ int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, f
   return DCQ_OK;
 }
 
-}  // extern "C"
+}  // namespace dcq

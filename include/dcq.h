@@ -287,6 +287,15 @@ int64_t dcq_cholesky_workspace_bytes(int64_t n);
 int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U, void* workspace,
                                int64_t workspace_bytes, int32_t* info, dcq_stream_t stream);
 
+/* dcq_cholesky_inverse_upper_static: the same routine for callers that cannot allocate device memory or pass a
+ * workspace -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
+ * counterpart in the reference.  The workspace is a 36 MiB array built into the library (one copy per GPU, held until
+ * the process ends), so n is limited to 2048 (DCQ_ERR_UNSUPPORTED beyond); nothing is allocated or freed.  Same
+ * kernels and results as dcq_cholesky_inverse_upper, bit for bit.  All calls on one GPU share that array: calls that
+ * overlap on one GPU (different streams or threads) race and must be serialised by the caller. */
+int dcq_cholesky_inverse_upper_static(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U,
+                                      int32_t* info, dcq_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Rotation (deepcompressor/calib/rotate.py:66-133, utils/math/hadamard.py:48-61).
  *
