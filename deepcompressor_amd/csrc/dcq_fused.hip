@@ -9,8 +9,6 @@
 //   * min/max over the team by xor butterflies, scale / zero computed redundantly in registers.
 //
 // Arithmetic is the reference's, operation by operation (IEEE division, round-half-even, no FMA contraction).
-#include <stdlib.h>
-
 #include "dcq_common.cuh"
 
 namespace dcq {
@@ -317,9 +315,8 @@ static int launch_fused(const FusedParams& p, hipStream_t stream) {
   // measured on MI355X: a persistent grid of 8192 workgroups (32 per CU), each team looping over its groups, streams
   // fastest from 60 MB to 1 GB (5.5-5.6 TB/s at 235 MB, 4.5-4.7 TB/s beyond the Infinity Cache); 2048 workgroups are
   // ~8 % slower, an un-looped grid 3-8 %; non-temporal loads / stores change nothing
-  const char* cap_env = getenv("DCQ_FUSED_GRID_CAP");
-  const int64_t cap = cap_env ? atoll(cap_env) : 8192;
-  if (blocks > cap) blocks = cap;
+  constexpr int64_t kGridCap = 8192;
+  if (blocks > kGridCap) blocks = kGridCap;
   if (p.chunks == 1) {
     hipLaunchKernelGGL((fused_int_kernel<ST, ZD, SK, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,
                        p);

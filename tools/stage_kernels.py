@@ -1,0 +1,30 @@
+"""The two HBM / VALU-bound stage kernels on their own, as a plain program for rocprofv3 passes:
+    fused fake-quantization of a 32768 x 8192 bf16 tensor (1.07 GB: past the 256 MiB Infinity Cache), 5 launches
+    101-candidate range search on 14336 x 4096 bf16 (Llama-3-8B gate_proj), 3 launches
+python3 tools/stage_kernels.py            (GPU box; rocprofv3 ... -- python3 tools/stage_kernels.py)
+"""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+from deepcompressor_amd.calib import calibrate_dynamic_range  # noqa: E402
+from deepcompressor_amd.data.common import TensorType  # noqa: E402
+
+dev = torch.device("cuda", 0)
+Quantizer, qcfg, rcfg, _ = bench.build_objects()
+q = Quantizer(qcfg, key="rate", develop_dtype=torch.float32)
+big = (torch.randn(32768, 8192, device=dev) * 0.02).to(torch.bfloat16)
+w = (torch.randn(14336, 4096, device=dev) * 0.02).to(torch.bfloat16)
+for _ in range(5):
+    q.quantize(big)
+torch.cuda.synchronize()
+for _ in range(3):
+    calibrate_dynamic_range(TensorType.Weights, rcfg, True, q, modules=[None], activations=None,
+                            weights=[nn.Parameter(w, requires_grad=False)])
+torch.cuda.synchronize()
+print("done")
