@@ -42,115 +42,110 @@ class QServePacker:
         return out
 
     def pack_scale(self, scale: torch.Tensor, zero: torch.Tensor | None = None, subscale: torch.Tensor | None = None):
-        scale = scale.view(-1)
-        n = scale.shape[0]
+        """Per-channel values flat; the per-group int8 ``subscale`` / ``zero`` tables transposed to [groups][channels]
+        with the 32 channels of a tile dealt as (2 packs, 8 lanes, 2 registers) instead of (2, 2, 8)."""
+        channels = scale.numel()
         if subscale is None:
-            zero = zero.view(-1)
-        else:
-            assert subscale.dtype == torch.int8, f"subscale should be torch.int8, but got {subscale.dtype}."
-            view = (n // self.mem_n, self.num_n_packs, self.n_pack_size, self.num_n_lanes, self.reg_n, -1)
-            subscale = subscale.view(view).permute(5, 0, 1, 3, 2, 4).contiguous().view(-1, n)
-            zero = zero.view(view).permute(5, 0, 1, 3, 2, 4).contiguous().view(-1, n)
-        return scale, zero, subscale
+            return scale.view(-1), zero.view(-1), None
+        assert subscale.dtype == torch.int8, f"subscale should be torch.int8, but got {subscale.dtype}."
+
+        def deal(table: torch.Tensor) -> torch.Tensor:
+            tiles = table.view(channels // self.mem_n, self.num_n_packs, self.n_pack_size, self.num_n_lanes,
+                               self.reg_n, -1)
+            return tiles.permute(5, 0, 1, 3, 2, 4).contiguous().view(-1, channels)
+
+        return scale.view(-1), deal(zero), deal(subscale)
+
+
+def _in_range(t: torch.Tensor, lo: float, hi: float, what: str) -> None:
+    """Converter invariant: every value of ``t`` lies in [lo, hi] (an AssertionError naming ``what`` otherwise)."""
+    vmin, vmax = float(t.min()), float(t.max())
+    assert lo <= vmin and vmax <= hi, f"{what} should lie in [{lo:g}, {hi:g}], got [{vmin:g}, {vmax:g}]."
+
+
+def _per_row(t: torch.Tensor, rows: int, cols: int = 1) -> torch.Tensor:
+    """A scalar, per-row or per-(row, group) parameter as a float32 [rows][cols][1] (cols == 1: [rows][1]) tensor."""
+    t = t.reshape(-1).expand(rows * cols) if t.numel() == 1 else t
+    t = t.reshape(rows, cols).contiguous()
+    return t.view(rows, cols, 1) if cols > 1 else t.view(rows, 1)
+
+
+def _unsigned4(codes: torch.Tensor, zero: torch.Tensor, step: torch.Tensor, zero_is_code: bool):
+    """Bring 4-bit codes and their zero point to the unsigned convention QServe stores.
+
+    ``zero_is_code`` (the checkpoint's PreScale zero): the zero point is itself a 4-bit code (signed ones are shifted
+    by 8), it is added to the codes and then expressed in units of the first-level grid (times ``step``).  Otherwise
+    the zero point already lives on that grid; signed codes are shifted by 8 and the zero point by 8 steps."""
+    if zero_is_code:
+        zero = zero + 8 if zero.min() < 0 else zero
+        _in_range(zero, 0, 15, "quantized zero point")
+        return codes + zero, zero * step
+    if codes.min() < 0:
+        return codes + 8, zero + 8 * step
+    return codes, zero
 
 
 def convert_to_qserve_w4x8y16_linear_weight(weight: torch.Tensor, scale: torch.Tensor, zero: torch.Tensor,
                                             subscale: torch.Tensor | None = None, zero_pre_scaled: bool = False):
-    """(packed weight int8 [oc][ic / 2], scale, zero, subscale) -- backend/qserve/utils.py:64-179."""
+    """(packed weight int8 [oc][ic / 2], scale, zero, subscale) with the results of backend/qserve/utils.py:64-179.
+
+    The 4-bit codes are recovered from the dequantized float16 weight: per channel ``round((w [+ z]) / s)``; per group
+    first the 8-bit level ``round(w / s)`` (checked against [-128, 127]), then ``(that [+ z]) / subscale`` inside each
+    group.  The order of the float32 operations is the reference's, so exact code * scale products come back as the
+    same integers."""
     dtype = weight.dtype
     assert dtype == torch.float16, "currently qserve only supports fp16."
     assert scale is not None, "scale tensor is required for quantization."
     assert zero is not None, "zero point tensor is required for quantization."
-    weight = weight.to(dtype=torch.float32)
-    scale = scale.to(dtype=torch.float32, device=weight.device)
-    zero = zero.to(dtype=torch.float32, device=weight.device)
     oc, ic = weight.shape
-    if scale.numel() == 1:
-        scale = scale.view(-1).expand(oc)
-    scale = scale.reshape(oc).contiguous().view(oc, 1)
-    if subscale is not None:  # per-group quantization: int8 first level, 4-bit second level
-        subscale = subscale.to(dtype=weight.dtype, device=weight.device)
+    dev = weight.device
+    w = weight.to(torch.float32)
+    s1 = _per_row(scale.to(dtype=torch.float32, device=dev), oc)
+    z = zero.to(dtype=torch.float32, device=dev)
+    if subscale is None:  # one float16 scale per output channel
+        z = _per_row(z, oc)
+        if zero_pre_scaled:
+            codes = (w / s1).round_()
+            codes, z = _unsigned4(codes, z.round(), s1, True)
+        else:
+            codes = ((w + z) / s1).round_()
+            codes, z = _unsigned4(codes, z, s1, False)
+        _in_range(codes, 0, 15, "quantized weight")
+        z = z.to(dtype)
+    else:  # int8 first level per channel, unsigned 4-bit second level per group
         assert subscale.numel() > 1, "subscale tensor is required for per-group quantization."
-        subscale = subscale.view(oc, -1, 1).round_()
-        ng = subscale.shape[1]
-        gs = ic // ng
-        assert ic == ng * gs, "input channel size should be divisible by group size."
-        if zero.numel() == 1:
-            zero = zero.view(1, 1).expand(oc, ng)
-        zero = zero.reshape(oc, ng).contiguous().view(oc, ng, 1).round_()
-        weight = weight.div_(scale).round_()
-        assert weight.min() >= -128, "first-level quantized weight should be greater than or equal to -128."
-        assert weight.max() <= 127, "first-level quantized weight should be less than or equal to 127."
-        weight = weight.view(oc, ng, gs)
-        if not zero_pre_scaled:  # zero point is int8
-            weight = weight.add_(zero)
-        weight = weight.div_(subscale)
-        if zero_pre_scaled:  # zero point is int4
-            if zero.min() < 0:  # sint4 zero point
-                zero = zero.add_(8)
-            assert zero.min() >= 0, "quantized zero point should be non-negative."
-            assert zero.max() <= 15, "quantized zero point should be less than 16."
-            weight = weight.add_(zero)
-            zero = zero.mul_(subscale)
-        elif weight.min() < 0:  # sint4 weight
-            weight = weight.add_(8)
-            zero = zero.add_(8 * subscale)
-        first_level = weight.mul(subscale)
-        assert first_level.min() >= 0, "first-level dequantize weight should be non-negative."
-        assert first_level.max() <= 255, "first-level dequantize weight should be less than 256."
-        del first_level
-        assert subscale.min() >= 0, "subscale should be non-negative."
-        assert subscale.max() <= 127, "subscale should be less than or equal to 127."
-        assert zero.min() >= 0, "quantized zero point should be non-negative."
-        assert zero.max() <= 255, "quantized zero point should be less than 256."
-        assert weight.min() >= 0, "quantized weight should be non-negative."
-        assert weight.max() <= 15, "quantized weight should be less than 16."
-        zero = -zero  # for group quantization QServe uses q * s + z = r instead of q * s - z = r
-        subscale = subscale.to(torch.int8)
-        zero = zero.to(torch.int8)
-    else:  # per-channel quantization
-        if zero.numel() == 1:
-            zero = zero.view(-1).expand(oc)
-        zero = zero.reshape(oc).contiguous().view(oc, 1)
-        if not zero_pre_scaled:  # zero point is fp16
-            weight = weight.add_(zero)
-        weight = weight.div_(scale).round_()
-        if zero_pre_scaled:  # zero point is int4
-            zero = zero.round_()
-            if zero.min() < 0:
-                zero = zero.add_(8)
-            assert zero.min() >= 0, "quantized zero point should be non-negative."
-            assert zero.max() <= 15, "quantized zero point should be less than 16."
-            weight = weight.add_(zero)
-            zero = zero.mul_(scale)
-        elif weight.min() < 0:
-            weight = weight.add_(8)
-            zero = zero.add_(8 * scale)
-        assert weight.min() >= 0, "quantized weight should be non-negative."
-        assert weight.max() <= 15, "quantized weight should be less than 16."
-        zero = zero.to(dtype=dtype)
-    scale = scale.to(dtype=dtype)
+        s2 = subscale.to(dtype=torch.float32, device=dev).view(oc, -1, 1).round()
+        groups = s2.shape[1]
+        assert ic % groups == 0, "input channel size should be divisible by group size."
+        z = _per_row(z, oc, groups).view(oc, groups, 1).round()
+        level1 = (w / s1).round_()
+        _in_range(level1, -128, 127, "first-level quantized weight")
+        level1 = level1.view(oc, groups, ic // groups)
+        if zero_pre_scaled:
+            codes, z = _unsigned4(level1 / s2, z, s2, True)
+        else:
+            codes, z = _unsigned4((level1 + z) / s2, z, s2, False)
+        _in_range(codes * s2, 0, 255, "first-level dequantize weight")
+        _in_range(s2, 0, 127, "subscale")
+        _in_range(z, 0, 255, "quantized zero point")
+        _in_range(codes, 0, 15, "quantized weight")
+        z = (-z).to(torch.int8)  # QServe's per-group convention is q * s + z
+        subscale = s2.to(torch.int8)
     packer = QServePacker()
-    weight = packer.pack_weight(weight.view(oc, ic).to(torch.uint8))
-    scale, zero, subscale = packer.pack_scale(scale=scale, zero=zero, subscale=subscale)
-    return weight, scale, zero, subscale
+    packed = packer.pack_weight(codes.reshape(oc, ic).to(torch.uint8))
+    out_scale, out_zero, out_subscale = packer.pack_scale(scale=s1.to(dtype), zero=z, subscale=subscale)
+    return packed, out_scale, out_zero, out_subscale
 
 
 def convert_to_qserve_w8x8y16_linear_weight(weight: torch.Tensor, scale: torch.Tensor):
-    """(int8 weight, float16 per-channel scale) -- backend/qserve/utils.py:182-210."""
-    dtype = weight.dtype
-    assert dtype == torch.float16, "currently qserve only supports fp16."
+    """(int8 weight, float16 per-channel scale) with the results of backend/qserve/utils.py:182-210."""
+    assert weight.dtype == torch.float16, "currently qserve only supports fp16."
     assert scale is not None, "scale tensor is required for quantization."
-    weight = weight.to(dtype=torch.float32)
-    scale = scale.to(dtype=torch.float32, device=weight.device)
     oc = weight.shape[0]
-    if scale.numel() == 1:
-        scale = scale.view(-1).expand(oc)
-    scale = scale.reshape(oc).contiguous().view(oc, 1)
-    weight = weight.div_(scale).round_()
-    assert weight.min() >= -128, "quantized weight should be greater than or equal to -128."
-    assert weight.max() <= 127, "quantized weight should be less than or equal to 127."
-    return weight.contiguous().to(torch.int8), scale.view(oc).to(dtype=dtype)
+    s = _per_row(scale.to(dtype=torch.float32, device=weight.device), oc)
+    codes = (weight.to(torch.float32) / s).round_()
+    _in_range(codes, -128, 127, "quantized weight")
+    return codes.contiguous().to(torch.int8), s.view(oc).to(torch.float16)
 
 
 def convert_to_qserve_state_dict(state_dict: dict[str, torch.Tensor], scale_dict: dict[str, torch.Tensor],

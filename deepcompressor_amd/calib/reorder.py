@@ -243,27 +243,29 @@ class ChannelOrderCalibrator:
         self.candidate_id += 1
 
     # ---- candidate in place (reorder.py:472-540)
+    def _quantize_in_candidate_order(self, tensor: torch.Tensor, dim: int, fake_quantize) -> torch.Tensor:
+        """``fake_quantize`` applied to ``tensor`` with its channels (dimension ``dim``) gathered into the candidate
+        order -- so the quantization groups are the candidate's -- and scattered back afterwards."""
+        order = self.candidate
+        if order is None:
+            return fake_quantize(tensor)
+        gathered = tensor.index_select(dim=dim, index=order.to(tensor.device))
+        return fake_quantize(gathered).index_select(dim=dim, index=self.candidate_inverse.to(tensor.device))
+
     def _process_x_in_xw(self, x: torch.Tensor, channels_dim=None) -> torch.Tensor:
+        """Inputs as the quantized layer would see them under the candidate order (calib/reorder.py:472-482)."""
         if not self.needs_x_quant_for_wgts:
             return x
-        if channels_dim is None:
-            channels_dim = self.x_quantizer.channels_dim
-        if self.candidate is not None:
-            x = x.index_select(dim=channels_dim, index=self.candidate.to(x.device))
-        x = self.x_quantizer.quantize(x, channels_dim=channels_dim).data
-        if self.candidate is not None:
-            x = x.index_select(dim=channels_dim, index=self.candidate_inverse.to(x.device))
-        return x
+        dim = self.x_quantizer.channels_dim if channels_dim is None else channels_dim
+        return self._quantize_in_candidate_order(
+            x, dim, lambda t: self.x_quantizer.quantize(t, channels_dim=dim).data)
 
     def _process_w_in_xw(self, w: torch.Tensor) -> torch.Tensor:
+        """Weights fake-quantized under the candidate order of their input channels (calib/reorder.py:484-492)."""
         if not self.needs_w_quant_for_wgts:
             return w
-        if self.candidate is not None:
-            w = w.index_select(dim=1, index=self.candidate.to(w.device))
-        w = self.w_quantizer.quantize(w.data, kernel=None, develop_dtype=self.develop_dtype).data
-        if self.candidate is not None:
-            w = w.index_select(dim=1, index=self.candidate_inverse.to(w.device))
-        return w
+        return self._quantize_in_candidate_order(
+            w, 1, lambda t: self.w_quantizer.quantize(t.data, kernel=None, develop_dtype=self.develop_dtype).data)
 
     def _process_wgts_centric_mod(self, wgts: list[nn.Parameter], mods: list[nn.Module], *, reorder_wgts,
                                   reorder_ipt_mods, reorder_opt_mods) -> None:

@@ -76,34 +76,6 @@ __global__ __launch_bounds__(256) void pack_nunchaku_kernel(const int8_t* __rest
   }
 }
 
-// TinyChat (AWQ W4A16) layout: 32 consecutive input channels of a row fold into eight 16-bit values (value b holds the
-// codes of channels b, 8 + b, 16 + b, 24 + b, lowest nibble first); the eight values of row 4 * r4 + rl and channel block
-// c32 land in output row r4 at column (c32 / 2) * 64 + rl * 16 + (c32 % 2) * 8.  One lane reads its 32 codes (32 B) and
-// writes its eight values (16 B) at once.
-__device__ inline uint2 interleave_bytes(uint32_t p, uint32_t q) {  // p3 p2 p1 p0, q3 q2 q1 q0 -> (q1 p1 q0 p0, q3 p3 q2 p2)
-  uint2 r;
-  r.x = (p & 0xffu) | ((q & 0xffu) << 8) | ((p & 0xff00u) << 8) | ((q & 0xff00u) << 16);
-  r.y = ((p >> 16) & 0xffu) | (((q >> 16) & 0xffu) << 8) | ((p >> 24) << 16) | ((q >> 24) << 24);
-  return r;
-}
-
-__global__ __launch_bounds__(256) void pack_tinychat_w4_kernel(const int8_t* __restrict__ codes, int64_t n, int64_t k,
-                                                               int16_t* __restrict__ out) {
-  const int64_t blocks32 = k / 32, lanes = n * blocks32;
-  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < lanes;
-       t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const int64_t row = t / blocks32, c32 = t % blocks32;
-    const uint4* src = reinterpret_cast<const uint4*>(codes + row * k + c32 * 32);
-    const uint4 lo = src[0], hi = src[1];  // channels 0..15, 16..31
-    const uint32_t m = 0x0f0f0f0fu;
-    const uint32_t p0 = (lo.x & m) | ((lo.z & m) << 4), q0 = (hi.x & m) | ((hi.z & m) << 4);  // b = 0..3
-    const uint32_t p1 = (lo.y & m) | ((lo.w & m) << 4), q1 = (hi.y & m) | ((hi.w & m) << 4);  // b = 4..7
-    const uint2 a = interleave_bytes(p0, q0), b = interleave_bytes(p1, q1);
-    int16_t* dst = out + (row / 4) * k + (c32 / 2) * 64 + (row % 4) * 16 + (c32 % 2) * 8;
-    *reinterpret_cast<uint4*>(dst) = make_uint4(a.x, a.y, b.x, b.y);
-  }
-}
-
 }  // namespace dcq
 
 using namespace dcq;
@@ -149,23 +121,6 @@ int dcq_pack_nunchaku(const int8_t* codes, int64_t n, int64_t k, int32_t bits, i
                        static_cast<hipStream_t>(stream), codes, n, k, reinterpret_cast<uint32_t*>(out));
   }
   DCQ_LAUNCH_CHECK("pack_nunchaku_kernel launch");
-  return DCQ_OK;
-}
-
-int dcq_pack_tinychat_w4(const int8_t* codes, int64_t n, int64_t k, int16_t* out, dcq_stream_t stream) {
-  DCQ_REQUIRE(n >= 0 && k >= 0, DCQ_ERR_ARGUMENT, "negative size");
-  DCQ_REQUIRE(n % 4 == 0 && k % 64 == 0, DCQ_ERR_UNSUPPORTED,
-              "TinyChat packs tiles of 4 output x 64 input channels (got %lld x %lld)", (long long)n, (long long)k);
-  if (n == 0 || k == 0) return DCQ_OK;
-  DCQ_REQUIRE(codes && out, DCQ_ERR_ARGUMENT, "NULL buffer");
-  DCQ_REQUIRE((reinterpret_cast<uintptr_t>(codes) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0,
-              DCQ_ERR_ARGUMENT, "buffers must be 16-byte aligned");
-  const int64_t lanes = n * (k / 32);
-  int64_t blocks = (lanes + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(pack_tinychat_w4_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), codes, n, k, out);
-  DCQ_LAUNCH_CHECK("pack_tinychat_w4_kernel launch");
   return DCQ_OK;
 }
 

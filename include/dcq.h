@@ -347,12 +347,6 @@ int dcq_pack_qserve_w4(const uint8_t* codes, int64_t n, int64_t k, int8_t* out, 
  * (int8) in the back end's fragment order.  n must be a multiple of 128, k of 128 (4 bits) or 64 (8 bits). */
 int dcq_pack_nunchaku(const int8_t* codes, int64_t n, int64_t k, int32_t bits, int8_t* out, dcq_stream_t stream);
 
-/* dcq_pack_tinychat_w4: pack_w4 of the TinyChat (AWQ W4A16) converter (deepcompressor/backend/tinychat/utils.py:45-54):
- * codes[n][k] (int8, one code per byte; the low 4 bits are kept) -> out[n / 4][k] (int16): every 32 input channels of
- * a row fold into eight 16-bit values (channels b, 8 + b, 16 + b, 24 + b in nibbles 0..3), and four rows interleave in
- * runs of 16 values per 64 input channels.  n must be a multiple of 4, k of 64; buffers 16-byte aligned. */
-int dcq_pack_tinychat_w4(const int8_t* codes, int64_t n, int64_t k, int16_t* out, dcq_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1565,70 +1565,6 @@ def gen_nunchaku(ref) -> None:
         json.dump(meta, f, indent=1)
 
 
-@torch.no_grad()
-def gen_tinychat(ref) -> None:
-    """The reference's TinyChat (AWQ W4A16) converter (backend/tinychat/utils.py:11-107, convert.py:14-101) on its
-    own quantizer outputs (uint4 with PostScale / PreScale zeros, groups of 128 / 64 / 32 and per channel), and
-    Nunchaku's W4A16 converter for AdaNorm layers built on it (backend/nunchaku/utils.py:341-368)."""
-    from deepcompressor.backend.nunchaku.utils import convert_to_nunchaku_w4x16_linear_weight
-    from deepcompressor.backend.tinychat.convert import convert_to_tinychat_state_dict
-    from deepcompressor.backend.tinychat.utils import ceil_num_groups, pack_w4
-
-    arrays, meta = {}, {"ceil_num_groups": {}}
-    g = torch.Generator().manual_seed(777)
-    for ic in (64, 128, 4096, 11008, 14336):
-        for gs in (32, 64, 128):
-            if ic % gs == 0:
-                meta["ceil_num_groups"][f"{ic}|{gs}"] = ceil_num_groups(ic, gs)
-    codes = torch.randint(0, 16, (24, 192), generator=g, dtype=torch.int32)
-    arrays["pack|codes"], arrays["pack|packed"] = codes.numpy().copy(), pack_w4(codes.clone()).numpy().copy()
-    plans = {
-        "g128_post_f16": (dict(dtype="uint4", zero="PostScale", groups=((1, 128),), sdt=("f16",)), "f16"),
-        "g64_post_bf16": (dict(dtype="uint4", zero="PostScale", groups=((1, 64),), sdt=("bf16",)), "bf16"),
-        "g32_pre_f16": (dict(dtype="uint4", zero="PreScale", groups=((1, 32),), sdt=("f16",)), "f16"),
-        "gchn_post_f16": (dict(dtype="uint4", zero="PostScale", groups=((1, -1),), sdt=("f16",)), "f16"),
-    }
-    for tag, (case, dt) in plans.items():
-        state, scales = {}, {}
-        for name, shape in (("layers.0.q_proj", (64, 256)), ("layers.0.down_proj", (96, 384))):
-            w = (torch.randn(*shape, generator=g) * 0.02).to(TORCH_DT[dt])
-            r = _build_quantizer(ref, case).quantize(w, return_with_dequant=True, return_with_quant=True)
-            state[f"{name}.weight"] = r.data
-            scales.update(r.scale.state_dict(f"{name}.weight.scale"))
-            zero_name = "scaled_zero" if case["zero"] == "PostScale" else "zero"
-            scales[f"{name}.weight.{zero_name}"] = r.zero if r.zero.ndim else r.zero.view(1)
-        state["layers.0.norm.weight"] = torch.ones(256, dtype=TORCH_DT[dt])
-        out = convert_to_tinychat_state_dict(state, scales)
-        for k, v in state.items():
-            arrays[f"{tag}|model|{k}"] = _np(v)
-        for k, v in scales.items():
-            arrays[f"{tag}|scale|{k}"] = _np(v)
-        for k, v in out.items():
-            arrays[f"{tag}|out|{k}"] = v.numpy().copy() if v.dtype == torch.int16 else _np(v)
-        meta[tag] = dict(case=dict(case), dtype=dt, out={k: [str(v.dtype), list(v.shape)] for k, v in out.items()})
-    # AdaNorm: sint4 weights (symmetric), the converter shifts the codes by the fixed zero 7
-    for tag, splits, shape in (("adanorm_single", 3, (96, 128)), ("adanorm_zero", 6, (192, 128)), ("plain", 1, (64, 256))):
-        w = (torch.randn(*shape, generator=g) * 0.02).to(torch.bfloat16)
-        r = _build_quantizer(ref, dict(dtype="sint4", zero=None, groups=((1, 64),), sdt=("bf16",))).quantize(
-            w, return_with_dequant=True, return_with_quant=True)
-        bias = torch.randn(shape[0], generator=g).to(torch.bfloat16)
-        arrays[f"w4x16|{tag}|weight"], arrays[f"w4x16|{tag}|scale"] = _np(r.data), _np(r.scale.data)
-        arrays[f"w4x16|{tag}|bias"] = _np(bias)
-        qw, qs, qz, qb = convert_to_nunchaku_w4x16_linear_weight(r.data.clone(), r.scale.data.clone(), bias=bias.clone(),
-                                                                 adanorm_splits=splits)
-        arrays[f"w4x16|{tag}|out_weight"] = qw.numpy().copy()
-        arrays[f"w4x16|{tag}|out_scale"], arrays[f"w4x16|{tag}|out_zero"] = _np(qs), _np(qz)
-        arrays[f"w4x16|{tag}|out_bias"] = _np(qb)
-        meta[f"w4x16|{tag}"] = dict(splits=splits, shape=list(shape), out_weight=[str(qw.dtype), list(qw.shape)])
-    np.savez_compressed(os.path.join(OUT, "tinychat.npz"), **arrays)
-    with open(os.path.join(OUT, "tinychat.json"), "w") as f:
-        json.dump(meta, f, indent=1)
-
-
-TINY_LLAMA = dict(vocab_size=128, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
-                  num_key_value_heads=2, max_position_embeddings=64)
-
-
 def gen_llm_layer_stages(ref) -> None:
     """The reference's rotation and smoothing stages (app/llm/quant/rotate.py:25-196, app/llm/quant/smooth.py:23-167)
     run on a two-layer random Llama (bf16, grouped-query attention): every parameter before and after the rotation,
@@ -1980,7 +1916,7 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "tinychat", "llm_layer_stages", "patch_linear", "ste", "smooth_tensor", "branch"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "llm_layer_stages", "patch_linear", "ste", "smooth_tensor", "branch"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
