@@ -183,6 +183,51 @@ __device__ __forceinline__ float from_code(float q, float s, float z) {
   return q * s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// IEEE-exact x / s for many x and one s.
+//
+// The hardware's own correctly-rounded float32 division is: y = refined reciprocal of s (rcp + one Newton
+// step), q0 = x*y, two residual corrections q <- q + (x - s*q)*y, wrapped in a pre-scaling / fix-up pair that
+// only matters when an intermediate could overflow or go subnormal.  The reciprocal part depends on s alone,
+// so it is hoisted out of the element loop, and the wrapping is dropped under a guard that makes it
+// unnecessary: 2^-60 <= s <= 2^60 and |x| <= 2^60.  (Then every intermediate of the corrections is a normal
+// number unless |x| < 2^-96, in which case |x / s| < 2^-36 and its last bit cannot change round(x / s [+ z]).)
+// Groups outside the guard take the plain division.  dcq_selftest_division checks the equivalence on the GPU.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Divisor {
+  float s, y;
+  bool fast;
+};
+
+__device__ __forceinline__ Divisor make_divisor(float s, float abs_bound) {
+  Divisor d;
+  d.s = s;
+  const float y0 = __builtin_amdgcn_rcpf(s);
+  const float e = __builtin_fmaf(-s, y0, 1.0f);
+  d.y = __builtin_fmaf(e, y0, y0);
+  d.fast = s >= 0x1p-60f && s <= 0x1p60f && abs_bound <= 0x1p60f;
+  return d;
+}
+
+__device__ __forceinline__ f32x2 div_fast2(f32x2 x, const Divisor& d) {
+  const f32x2 y = {d.y, d.y}, ns = {-d.s, -d.s};
+  f32x2 q = x * y;
+  f32x2 r = __builtin_elementwise_fma(ns, q, x);
+  q = __builtin_elementwise_fma(r, y, q);
+  r = __builtin_elementwise_fma(ns, q, x);
+  return __builtin_elementwise_fma(r, y, q);
+}
+
+__device__ __forceinline__ float div_fast(float x, const Divisor& d) {
+  float q = x * d.y;
+  float r = __builtin_fmaf(-d.s, q, x);
+  q = __builtin_fmaf(r, d.y, q);
+  r = __builtin_fmaf(-d.s, q, x);
+  return __builtin_fmaf(r, d.y, q);
+}
+
 // xor-butterfly reductions over `width` adjacent lanes (width a power of two <= 64)
 __device__ __forceinline__ float team_max(float v, int width) {
   for (int off = width >> 1; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));

@@ -423,17 +423,233 @@ struct SweepParams {
   float* Err;  // [R][ld_err], 128 columns used
   int64_t ld_err;
   int32_t u_quads;  // the block of U may be read as aligned float4
+  int32_t fast_layout;  // Q and Err rows of the block take aligned float4 stores
+  int32_t rows_per_block;  // rows a workgroup sweeps at a time (its first 16 * rows_per_block threads; the rest only stage)
 };
 
+#ifdef DCQ_STAMP
+__device__ unsigned long long g_stamp[4];  // timing-only builds: shader cycles / 100 MHz ticks of one wave's column loop
+#endif
+
+// DPP moves inside every 16-lane row: the value of the row's lane 0 to all its lanes (row_newbcast:0), and a rotation
+// by one lane towards lane 0 (lane l takes lane l + 1's value, lane 15 takes lane 0's: row_ror:15).  No LDS round trip.
+__device__ __forceinline__ float row_first(float v) {
+  const int bits = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(bits, bits, 0x150, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_rotate_down(float v) {
+  const int bits = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(bits, bits, 0x12F, 0xf, 0xf, false));
+}
+
+// The guard maximum of a column as volatile assembly, so it stays inside its column: left to the compiler such
+// by-products are sunk to the end of the chain, which keeps their inputs alive and spills them to scratch memory.
+__device__ __forceinline__ void track_max_abs(float& worst, float a, float b) {
+  asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(worst) : "v"(a), "v"(b));
+}
+
+// One row per 16-lane team, the block's 128 columns in registers (8 per lane).  Per column the serial chain is
+//   clamp -> (+ zero) -> / scale -> round -> clamp -> dequantize -> error / U[c][c] -> broadcast -> update,
+// and a wave has nothing else to do while it runs, so its length in dependent instructions is the kernel's time.
+//
+// FAST (whole 128-column blocks, aligned buffers): both divisions use the hoisted-reciprocal form (bit-identical to
+// IEEE division inside its guard, see make_divisor) and the broadcast is a DPP move.  A DPP move names its source
+// lane in the instruction, so instead of unrolling all 128 columns (the straight-line code then outgrows the
+// instruction cache and the wave waits for its own instructions) the lanes' columns rotate: after a lane's 8 columns
+// are done every lane hands its state to its lower neighbour, and the lane whose columns are swept is always lane 0.
+// Lane 0 stores the 8 codes and errors of each step straight to memory.  The guard on the dividends (|x| <= 2^60) is
+// checked after the fact: the caller reruns the rows through the plain form when `overflow` comes back set, which
+// real weights never do.
+// The lane's 8 weights of row rr in this block with their scales / zeros (looked up through the act-order permutation).
+struct RowState {
+  float w[kSweepPerLane], s[kSweepPerLane], z[kSweepPerLane];
+};
+
+template <int ZD>
+__device__ __forceinline__ RowState load_row_state(const SweepParams& p, int64_t rr, int tl) {
+  RowState r;
+  const int64_t rg = rr / p.row_group_size;
+#pragma unroll
+  for (int i = 0; i < kSweepPerLane; ++i) {
+    const int col = tl * kSweepPerLane + i;
+    const bool in = col < p.bc;
+    r.w[i] = in ? p.W[rr * p.ldw + p.c0 + col] : 0.0f;
+    const int64_t cg = in ? p.perm[p.c0 + col] / p.col_group_size : 0;
+    r.s[i] = p.scale[rg * p.col_groups + cg];
+    r.z[i] = ZD == DCQ_ZERO_NONE ? 0.0f : (p.zero ? p.zero[rg * p.col_groups + cg] : p.zero_scalar);
+  }
+  return r;
+}
+
+template <int ZD, bool INT_Q, bool FAST>
+__device__ __forceinline__ void sweep_rows(const SweepParams& p, const float* u_lds, const float* diag_s,
+                                           const float* diag_y, const float* cb, const RowState& state, int64_t rr,
+                                           bool live, int tl, float (&q)[kSweepPerLane], float (&er)[kSweepPerLane],
+                                           bool& overflow) {
+  const dcq_step& st = p.step;
+  float w[kSweepPerLane], s[kSweepPerLane], z[kSweepPerLane];
+#pragma unroll
+  for (int i = 0; i < kSweepPerLane; ++i) {
+    w[i] = state.w[i];
+    s[i] = state.s[i];
+    z[i] = state.z[i];
+    q[i] = 0.0f;
+    er[i] = 0.0f;
+  }
+  if (FAST) {
+    float y[kSweepPerLane];  // refined reciprocals of the scales
+    float worst = 0.0f;      // largest dividend seen by this lane
+    bool scales_ok = true;
+#pragma unroll
+    for (int i = 0; i < kSweepPerLane; ++i) {
+      const Divisor d = make_divisor(s[i], 0.0f);
+      y[i] = d.y;
+      scales_ok = scales_ok && d.fast;
+    }
+    // RangeBound as one median: an absent bound is an infinity, which leaves every finite value alone
+    const float bound_lo = p.has_bound_min ? p.bound_min : -INFINITY, bound_hi = p.has_bound_max ? p.bound_max : INFINITY;
+    float* q_out = p.Q + rr * p.ldw + p.c0;
+    float* e_out = p.Err + rr * p.ld_err;
+#ifdef DCQ_STAMP
+    const uint64_t st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll 1
+    for (int step = 0; step < kSweepTeam; ++step) {
+      // this lane now holds the columns of lane (tl + step) mod 16; row c of U, those 8 entries
+      const float* u_lane = u_lds + (step * kSweepPerLane) * kSweepCols + ((tl + step) & (kSweepTeam - 1)) * kSweepPerLane;
+      // all LDS operands of the step's 8 columns in one burst (one wait per step instead of one inside every column's
+      // chain): the 8 rows of U and the reciprocals of their diagonal entries
+      float4 ur[kSweepPerLane][2];
+#pragma unroll
+      for (int i = 0; i < kSweepPerLane; ++i) {
+        ur[i][0] = *reinterpret_cast<const float4*>(u_lane + i * kSweepCols);
+        ur[i][1] = *reinterpret_cast<const float4*>(u_lane + i * kSweepCols + 4);
+      }
+      const float4 yd0 = *reinterpret_cast<const float4*>(diag_y + step * kSweepPerLane);
+      const float4 yd1 = *reinterpret_cast<const float4*>(diag_y + step * kSweepPerLane + 4);
+      const float yd[8] = {yd0.x, yd0.y, yd0.z, yd0.w, yd1.x, yd1.y, yd1.z, yd1.w};
+      float qv[kSweepPerLane], ev[kSweepPerLane];
+#pragma unroll
+      for (int i = 0; i < kSweepPerLane; ++i) {
+        float a = __builtin_amdgcn_fmed3f(w[i], bound_lo, bound_hi);
+        if (ZD == DCQ_ZERO_POST_SCALE) a = a + z[i];
+        Divisor dq;
+        dq.s = s[i];
+        dq.y = y[i];
+        float t = div_fast(a, dq);
+        if (ZD == DCQ_ZERO_PRE_SCALE) t = t + z[i];
+        const float qi = INT_Q ? __builtin_amdgcn_fmed3f(rintf(t), st.tensor.lo, st.tensor.hi)
+                               : apply_rounding(st.tensor, t, cb);
+        const float d = from_code<ZD>(qi, s[i], z[i]);
+        const float diff = w[i] - d;
+        track_max_abs(worst, a, diff);
+        // in lane 0 entry i of its 8 entries of row c is the diagonal U[c][c]: the error that lane forms is the one
+        // to broadcast (the other lanes' quotients are never looked at)
+        const float4 u0 = ur[i][0], u1 = ur[i][1];
+        const float uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        Divisor dc;
+        dc.s = uu[i];
+        dc.y = yd[i];
+        const float e_own = div_fast(diff, dc);
+        qv[i] = qi;
+        ev[i] = e_own;
+        const float e = row_first(e_own);
+        // every lane updates: columns at or left of c are finished (their codes and errors are taken), so what
+        // happens to them no longer matters.  One fused multiply-add per element (two elements per instruction)
+        const f32x2 ne = {-e, -e};
+#pragma unroll
+        for (int k = 0; k < kSweepPerLane; k += 2) {
+          const f32x2 wk = {w[k], w[k + 1]}, uk = {uu[k], uu[k + 1]};
+          const f32x2 r = __builtin_elementwise_fma(ne, uk, wk);
+          w[k] = r.x;
+          w[k + 1] = r.y;
+        }
+      }
+      if (tl == 0 && live) {
+        *reinterpret_cast<float4*>(q_out + step * kSweepPerLane) = make_float4(qv[0], qv[1], qv[2], qv[3]);
+        *reinterpret_cast<float4*>(q_out + step * kSweepPerLane + 4) = make_float4(qv[4], qv[5], qv[6], qv[7]);
+        *reinterpret_cast<float4*>(e_out + step * kSweepPerLane) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+        *reinterpret_cast<float4*>(e_out + step * kSweepPerLane + 4) = make_float4(ev[4], ev[5], ev[6], ev[7]);
+      }
+#pragma unroll
+      for (int k = 0; k < kSweepPerLane; ++k) {
+        w[k] = row_rotate_down(w[k]);
+        s[k] = row_rotate_down(s[k]);
+        y[k] = row_rotate_down(y[k]);
+        if (ZD != DCQ_ZERO_NONE) z[k] = row_rotate_down(z[k]);
+      }
+    }
+#ifdef DCQ_STAMP
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      g_stamp[0] = __builtin_amdgcn_s_memtime() - st_c0;
+      g_stamp[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+#endif
+    overflow = !scales_ok || !(worst <= 0x1p60f);
+    return;
+  }
+  for (int owner = 0; owner < kSweepTeam; ++owner) {
+    if (owner * kSweepPerLane >= p.bc) break;  // uniform
+#pragma unroll
+    for (int i = 0; i < kSweepPerLane; ++i) {
+      const int c = owner * kSweepPerLane + i;
+      if (c < p.bc) {  // uniform
+        // every lane evaluates its own slot i; only the owner's value is used
+        float x = w[i];
+        if (p.has_bound_min) x = fmaxf(x, p.bound_min);
+        if (p.has_bound_max) x = fminf(x, p.bound_max);
+        const float t = to_code_input<ZD>(x, s[i], z[i]);
+        const float qi = INT_Q ? round_int(t, st.tensor.lo, st.tensor.hi) : apply_rounding(st.tensor, t, cb);
+        const float d = from_code<ZD>(qi, s[i], z[i]);
+        const float ucc = diag_s[c];
+        const float e_own = (w[i] - d) / ucc;
+        if (tl == owner) {
+          q[i] = qi;
+          er[i] = e_own;
+        }
+        const float e = __shfl(e_own, owner, kSweepTeam);
+        if (tl >= owner) {
+          const float4 u0 = *reinterpret_cast<const float4*>(u_lds + c * kSweepCols + tl * kSweepPerLane);
+          const float4 u1 = *reinterpret_cast<const float4*>(u_lds + c * kSweepCols + tl * kSweepPerLane + 4);
+          const float uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+          for (int k = 0; k < kSweepPerLane; ++k) {
+            // columns <= c of the owner lane see u = 0 below the diagonal except the diagonal itself,
+            // whose update is harmless (that column is finished); fused, as in the fast form
+            w[k] = __builtin_fmaf(-e, uu[k], w[k]);
+          }
+        }
+      }
+    }
+  }
+  overflow = false;
+}
+
 template <int ZD, bool INT_Q>
-__global__ __launch_bounds__(kSweepThreads) void gptq_sweep_kernel(const SweepParams p) {
+__global__ __launch_bounds__(kSweepThreads, 4) void gptq_sweep_kernel(const SweepParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
+#ifdef DCQ_STAMP
+  const uint64_t st_k0 = __builtin_amdgcn_s_memrealtime();
+#endif
   float* u_lds = reinterpret_cast<float*>(smem);           // [128][128], rows >= bc / cols >= bc zero
   float* cb = u_lds + kSweepCols * kSweepCols;             // tensor codebook [256]
+  float* diag_s = cb + 256;                                // U[c][c] of the block's columns [128]
+  float* diag_y = diag_s + kSweepCols;                     // their refined reciprocals [128]
+  int* diag_ok = reinterpret_cast<int*>(diag_y + kSweepCols);  // [1]: every diagonal entry is inside the fast guard
   // stage the diagonal block of U four columns at a time; entries left of the diagonal are never used with a
   // non-zero meaning, so quads wholly below it are written as zeros without touching memory
   const int threads = static_cast<int>(blockDim.x);
   const bool quads = p.u_quads != 0;
+  const int tl = threadIdx.x & (kSweepTeam - 1);
+  const int team = threadIdx.x / kSweepTeam;
+  const int teams_per_block = p.rows_per_block;
+  // the first rows' weights, and their scales behind two dependent look-ups, are requested before the block of U is
+  // staged, so their memory latency passes behind the staging
+  const bool sweeps = team < teams_per_block;  // (whole waves: rows_per_block is a multiple of 4)
+  const int64_t first_row = static_cast<int64_t>(blockIdx.x) * teams_per_block + team;
+  RowState state = load_row_state<ZD>(p, sweeps && first_row < p.R ? first_row : 0, tl);
+  if (threadIdx.x == 0) *diag_ok = 1;
+#pragma unroll 8
   for (int e = threadIdx.x; e < kSweepCols * kSweepCols / 4; e += threads) {
     const int r = e / (kSweepCols / 4), c = (e % (kSweepCols / 4)) * 4;
     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -456,63 +672,34 @@ __global__ __launch_bounds__(kSweepThreads) void gptq_sweep_kernel(const SweepPa
   if (!INT_Q)
     for (int i = threadIdx.x; i < p.step.tensor.codebook_size; i += threads) cb[i] = p.step.tensor.codebook[i];
   __syncthreads();
+  for (int c = threadIdx.x; c < kSweepCols; c += threads) {
+    const float ucc = c < p.bc ? u_lds[c * kSweepCols + c] : 1.0f;
+    const Divisor d = make_divisor(ucc, 0.0f);
+    diag_s[c] = ucc;
+    diag_y[c] = d.y;
+    if (!d.fast) *diag_ok = 0;  // (same value from every writer)
+  }
+  __syncthreads();
+  const bool fast_block = *diag_ok != 0 && p.bc == kSweepCols && p.fast_layout != 0;
+#ifdef DCQ_STAMP
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_stamp[2] = __builtin_amdgcn_s_memrealtime() - st_k0;
+#endif
 
-  const int tl = threadIdx.x & (kSweepTeam - 1);
-  const int team = threadIdx.x / kSweepTeam;
-  const int teams_per_block = threads / kSweepTeam;
-  const dcq_step& st = p.step;
+  if (!sweeps) return;  // staging helpers are done (no barrier follows)
   for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * teams_per_block; row0 < p.R;
        row0 += static_cast<int64_t>(gridDim.x) * teams_per_block) {
     const int64_t row = row0 + team;
     const bool live = row < p.R;
     const int64_t rr = live ? row : 0;
-    float w[kSweepPerLane], s[kSweepPerLane], z[kSweepPerLane], q[kSweepPerLane], er[kSweepPerLane];
-    const int64_t rg = rr / p.row_group_size;
-#pragma unroll
-    for (int i = 0; i < kSweepPerLane; ++i) {
-      const int col = tl * kSweepPerLane + i;
-      const bool in = col < p.bc;
-      w[i] = in ? p.W[rr * p.ldw + p.c0 + col] : 0.0f;
-      const int64_t cg = in ? p.perm[p.c0 + col] / p.col_group_size : 0;
-      s[i] = p.scale[rg * p.col_groups + cg];
-      z[i] = ZD == DCQ_ZERO_NONE ? 0.0f : (p.zero ? p.zero[rg * p.col_groups + cg] : p.zero_scalar);
-      q[i] = 0.0f;
-      er[i] = 0.0f;
-    }
-    for (int owner = 0; owner < kSweepTeam; ++owner) {
-      if (owner * kSweepPerLane >= p.bc) break;  // uniform
-#pragma unroll
-      for (int i = 0; i < kSweepPerLane; ++i) {
-        const int c = owner * kSweepPerLane + i;
-        if (c < p.bc) {  // uniform
-          // every lane evaluates its own slot i; only the owner's value is used
-          float x = w[i];
-          if (p.has_bound_min) x = fmaxf(x, p.bound_min);
-          if (p.has_bound_max) x = fminf(x, p.bound_max);
-          const float t = to_code_input<ZD>(x, s[i], z[i]);
-          const float qi = INT_Q ? round_int(t, st.tensor.lo, st.tensor.hi) : apply_rounding(st.tensor, t, cb);
-          const float d = from_code<ZD>(qi, s[i], z[i]);
-          const float ucc = u_lds[c * kSweepCols + c];
-          const float e_own = (w[i] - d) / ucc;
-          if (tl == owner) {
-            q[i] = qi;
-            er[i] = e_own;
-          }
-          const float e = __shfl(e_own, owner, kSweepTeam);
-          if (tl >= owner) {
-            const float4 u0 = *reinterpret_cast<const float4*>(u_lds + c * kSweepCols + tl * kSweepPerLane);
-            const float4 u1 = *reinterpret_cast<const float4*>(u_lds + c * kSweepCols + tl * kSweepPerLane + 4);
-            const float uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-#pragma unroll
-            for (int k = 0; k < kSweepPerLane; ++k) {
-              // columns <= c of the owner lane see u = 0 below the diagonal except the diagonal itself,
-              // whose update is harmless (that column is finished)
-              w[k] = w[k] - e * uu[k];
-            }
-          }
-        }
-      }
-    }
+    if (row != first_row) state = load_row_state<ZD>(p, rr, tl);
+    float q[kSweepPerLane], er[kSweepPerLane];
+    bool overflow = true;
+    if (fast_block) sweep_rows<ZD, INT_Q, true>(p, u_lds, diag_s, diag_y, cb, state, rr, live, tl, q, er, overflow);
+#ifdef DCQ_STAMP
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_stamp[3] = __builtin_amdgcn_s_memrealtime() - st_k0;
+#endif
+    if (!__any(overflow)) continue;  // (uniform over the wave) the fast form has stored its results itself
+    sweep_rows<ZD, INT_Q, false>(p, u_lds, diag_s, diag_y, cb, state, rr, live, tl, q, er, overflow);
     if (live) {
 #pragma unroll
       for (int i = 0; i < kSweepPerLane; ++i) {
@@ -529,6 +716,12 @@ __global__ __launch_bounds__(kSweepThreads) void gptq_sweep_kernel(const SweepPa
 using namespace dcq;
 
 extern "C" {
+
+#ifdef DCQ_STAMP
+int dcq_debug_read_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dcq::g_stamp), 32) == hipSuccess ? 0 : -3;
+}
+#endif
 
 void dcq_profile_next_hessian(void* start, void* stop) {
   g_prof_start = static_cast<hipEvent_t>(start);
@@ -641,14 +834,20 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
   p.Q = Q;
   p.Err = Err;
   p.ld_err = ld_err;
-  const size_t lds = kSweepCols * kSweepCols * 4 + 256 * 4;
+  const size_t lds = kSweepCols * kSweepCols * 4 + 256 * 4 + 2 * kSweepCols * 4 + 16;
   p.u_quads = (reinterpret_cast<uintptr_t>(U) & 15u) == 0 && C % 4 == 0 && c0 % 4 == 0;
+  p.fast_layout = ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(Err)) & 15u) == 0 && ldw % 4 == 0 &&
+                  ld_err % 4 == 0 && c0 % 4 == 0;
   // One column step costs a wave the same whether 4 or 1 of its rows are live, and the 64 KiB block of U lets two
   // workgroups share a CU: spread the rows over 512 workgroups (two per CU) of whole waves, at most 8 waves each.
-  int64_t rows_per_block = (R + 511) / 512;
+  // Up to 8192 rows one workgroup per CU does as well (a wave per SIMD either way) and stages the block with twice
+  // the threads.
+  int64_t rows_per_block = R <= 8192 ? (R + 255) / 256 : (R + 511) / 512;
   rows_per_block = (rows_per_block + 3) / 4 * 4;
   if (rows_per_block > kSweepThreads / kSweepTeam) rows_per_block = kSweepThreads / kSweepTeam;
-  const int sweep_threads = static_cast<int>(rows_per_block) * kSweepTeam;
+  // at least 4 waves per workgroup: with fewer rows the extra waves only help staging the 64 KiB block of U
+  const int sweep_threads = static_cast<int>(rows_per_block) * kSweepTeam < 256 ? 256 : static_cast<int>(rows_per_block) * kSweepTeam;
+  p.rows_per_block = static_cast<int32_t>(rows_per_block);
   int64_t blocks = (R + rows_per_block - 1) / rows_per_block;
   if (blocks > 1024) blocks = 1024;
   const bool int_q = step->tensor.kind == DCQ_ROUND_INT;
