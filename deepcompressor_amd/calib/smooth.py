@@ -241,13 +241,16 @@ class SmoothCalibrator:
     def get_best(self) -> torch.Tensor:
         return self.best_scale
 
-    def ask(self) -> torch.Tensor:
-        alpha, beta = self.alpha_beta_pairs[self.candidate_id % len(self.alpha_beta_pairs)]
-        a_span, b_span = self.span_pairs[self.candidate_id // len(self.alpha_beta_pairs)]
+    def _candidate_scale(self, candidate_id: int) -> torch.Tensor:
+        """The candidate_id-th scale of the grid: (alpha, beta) pairs inside each pair of spans."""
+        alpha, beta = self.alpha_beta_pairs[candidate_id % len(self.alpha_beta_pairs)]
+        a_span, b_span = self.span_pairs[candidate_id // len(self.alpha_beta_pairs)]
         if alpha == 0 and beta == 0:
-            self.candidate = torch.ones_like(a_span, dtype=self.develop_dtype)
-        else:
-            self.candidate = get_smooth_scale(alpha_base=a_span, beta_base=b_span, alpha=alpha, beta=beta)
+            return torch.ones_like(a_span, dtype=self.develop_dtype)
+        return get_smooth_scale(alpha_base=a_span, beta_base=b_span, alpha=alpha, beta=beta)
+
+    def ask(self) -> torch.Tensor:
+        self.candidate = self._candidate_scale(self.candidate_id)
         return self.candidate
 
     @staticmethod
@@ -318,6 +321,12 @@ class SmoothCalibrator:
             return x
         channels_dim = self.x_quantizer.channels_dim if channels_dim is None else channels_dim
         dtype = x.dtype
+        if self.develop_dtype == torch.float32 and channels_dim in (-1, x.ndim - 1):
+            # the three steps in one pass over x (bit-identical), when the quantizer's configuration allows it
+            fused = self.x_quantizer.smooth_candidates(x, self.candidate, divide_first=True, channels_dim=channels_dim,
+                                                       default_dtype=dtype)
+            if fused is not None:
+                return fused
         xs = scale_channels(x, self.candidate, channels_dim, divide=True, out_dtype=self.develop_dtype)
         xq = self.x_quantizer.quantize(xs, channels_dim=channels_dim, default_dtype=dtype,
                                        develop_dtype=self.develop_dtype).data
@@ -329,6 +338,11 @@ class SmoothCalibrator:
             return w
         dtype = w.dtype
         channels_dim = 1 if self.w_quantizer.channels_dim is None else self.w_quantizer.channels_dim
+        if self.develop_dtype == torch.float32 and w.ndim == 2 and channels_dim == 1:
+            fused = self.w_quantizer.smooth_candidates(w, self.candidate, divide_first=False, channels_dim=None,
+                                                       default_dtype=dtype)
+            if fused is not None:
+                return fused
         ws = scale_channels(w, self.candidate, channels_dim, divide=False, out_dtype=self.develop_dtype)
         wq = self.w_quantizer.quantize(ws, kernel=None, default_dtype=dtype, develop_dtype=self.develop_dtype).data
         return scale_channels(wq, self.candidate, channels_dim, divide=True, out_dtype=dtype)
@@ -498,12 +512,18 @@ class SmoothCalibrator:
                 for o, w, view in zip(origs, wgts, views)]
         self.reset(x_wgts=x_wgts, x_acts=x_acts)
         degree = float(self.config.degree)
+        # every candidate of every weight from ONE read of the weight, when the fused kernel covers the configuration
+        # (then the candidates' errors are looked up below instead of being computed one candidate at a time)
+        table = self._all_candidates_tensor_error(wgts, origs, degree)
         while not self.is_done():
             self.ask()
             errors = []
-            for w, view, ref in zip(wgts, views, refs, strict=True):
-                a2d, _ = engine.canonical_groups(self._process_w_in_xw(w), view)
-                raw = engine.group_error(a2d, ref, degree).view(view[::2]).double()
+            for index, (w, view, ref) in enumerate(zip(wgts, views, refs, strict=True)):
+                if table is not None:
+                    raw = table[index][self.candidate_id + self.iter * self.population_size].view(view[::2]).double()
+                else:
+                    a2d, _ = engine.canonical_groups(self._process_w_in_xw(w), view)
+                    raw = engine.group_error(a2d, ref, degree).view(view[::2]).double()
                 if self.granularity == SearchBasedCalibGranularity.Layer:
                     total = raw.sum().view(-1)
                 else:  # one error per group of input channels (Group is turned into ChannelGroup by the config)
@@ -511,6 +531,26 @@ class SmoothCalibrator:
                 errors.append(total.to(w.dtype))  # (weights are whole on every process: nothing to reduce)
             self.tell(errors)
         return self.get_best()
+
+    def _all_candidates_tensor_error(self, wgts: list[torch.Tensor], origs: list[torch.Tensor], degree: float):
+        """Per weight the float32 [candidates][groups] table of |Q(w s) / s - w|^degree sums, or None when a weight is
+        compared with something other than itself, or the quantizer is outside the fused kernel."""
+        if (not self.needs_w_quant_for_wgts or self.develop_dtype != torch.float32 or self.num_iters != 1
+                or any(o is not w for o, w in zip(origs, wgts))):
+            return None
+        channels_dim = 1 if self.w_quantizer.channels_dim is None else self.w_quantizer.channels_dim
+        if channels_dim != 1 or any(w.ndim != 2 for w in wgts):
+            return None
+        # (the candidate list does not depend on the errors)
+        scales = torch.stack([self._candidate_scale(cid).to(torch.float32) for cid in range(self.population_size)])
+        tables = []
+        for w in wgts:
+            errors = self.w_quantizer.smooth_candidates(w, scales, divide_first=False, channels_dim=None,
+                                                        default_dtype=w.dtype, errors_degree=degree)
+            if errors is None:
+                return None
+            tables.append(errors)
+        return tables
 
     def _calibrate_products(self, x_wgts: list[nn.Parameter], x_acts: TensorsCache | None,
                             orig_x_wgts: list[tuple[nn.Parameter, torch.Tensor]] | None,

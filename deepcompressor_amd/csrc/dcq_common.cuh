@@ -26,6 +26,10 @@ int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t
                          const float* range_min, int has_ratio, float ratio, void* dequant, float* codes, float* scale,
                          float* zero, hipStream_t stream);
 
+// float -> storage dtype -> double of a power's exponent: torch rounds the scalar exponent of Tensor.pow_ to the tensor's
+// dtype (dcq_search.hip)
+double round_degree_to_storage(double degree, int storage);
+
 #define DCQ_REQUIRE(cond, code, ...) \
   do {                               \
     if (!(cond)) {                   \

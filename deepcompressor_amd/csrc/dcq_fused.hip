@@ -368,6 +368,188 @@ int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t
   }
 }
 
+// =============================================================================================
+// Smoothing candidates, fused (deepcompressor/calib/smooth.py:504-530): what the reference does to a weight as
+//     w.mul(s) -> fake-quantize -> div(s) -> cast                    (mode 0)
+// and to an activation as
+//     x.div(s) -> fake-quantize -> mul(s) -> cast                    (mode 1)
+// with s a per-channel scale, float32 in between, happens here in registers: one read of the tensor, and either one
+// write of the processed tensor (one candidate) or no write at all -- then, for each of K candidate scale vectors, the
+// group's error sum |processed - original|^degree evaluated in the tensor's dtype (the TensorError objective,
+// calib/search.py:779-787), every candidate from the same registers.  Same team / chunk structure as the kernel above.
+// =============================================================================================
+struct SmoothParams {
+  FusedParams f;
+  const float* chan_scale;  // [K][C]
+  int64_t C;
+  int32_t groups_per_row;   // C / S
+  int32_t divide_first;     // mode 1
+  int32_t K;
+  float* errors;            // [K][G] float32 sums (unrounded), or NULL
+  const uint16_t* table;    // 16-bit storage: |d|^degree by bit pattern, or NULL when the degree is 2
+  float degree;
+};
+
+template <int ST>
+__device__ __forceinline__ float error_term(float processed, float original, const SmoothParams& p) {
+  // `processed` is already rounded to the storage type; difference, magnitude and power are each rounded to it too
+  const float d = processed - original;
+  if constexpr (ST == DCQ_F32) {
+    const float m = fabsf(d);
+    return p.degree == 2.0f ? m * m : powf(m, p.degree);
+  } else {
+    const float m = fabsf(Storage<ST>::round(d));
+    if (p.table == nullptr) return Storage<ST>::round(m * m);
+    const uint16_t bits = Storage<ST>::store(m) & 0x7fffu;
+    return Storage<ST>::load(p.table[bits]);
+  }
+}
+
+template <int ST, int ZD, int SK, bool SINGLE>
+__global__ __launch_bounds__(256) void smooth_int_kernel(const SmoothParams sp) {
+  using E = Elem<ST>;
+  using raw_t = typename E::raw_t;
+  constexpr int VEC = E::kVec;
+  const FusedParams& p = sp.f;
+  const int TL = p.team_lanes;
+  const int tl = threadIdx.x & (TL - 1);
+  const int64_t team0 = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> p.team_shift;
+  const int64_t nteams = (static_cast<int64_t>(gridDim.x) * 256) >> p.team_shift;
+  const raw_t* xin = static_cast<const raw_t*>(p.x);
+  raw_t* out = static_cast<raw_t*>(p.dequant);
+  const int64_t raws_per_group = p.S / VEC;
+  const int chunks = SINGLE ? 1 : p.chunks;
+  // whole waves iterate together (the trip count is taken from the wave's first team), dead teams redo group 0
+  const int64_t wave_team0 = __shfl(team0, 0, kWave);
+  for (int64_t gw = wave_team0, g0 = team0; gw < p.G; gw += nteams, g0 += nteams) {
+    const bool live = g0 < p.G;
+    const int64_t g = live ? g0 : 0;
+    const raw_t* xg = xin + g * raws_per_group;
+    const int64_t c_base = (g % sp.groups_per_row) * p.S;
+    raw_t keep;
+    if (SINGLE) keep = xg[tl];
+    for (int k = 0; k < sp.K; ++k) {
+      const float* cs = sp.chan_scale + static_cast<int64_t>(k) * sp.C + c_base;
+      // ---- pass 1: range of the smoothed values
+      float mx = ZD == DCQ_ZERO_NONE ? 0.0f : -INFINITY, mn = INFINITY;
+      for (int c = 0; c < chunks; ++c) {
+        const int64_t off = static_cast<int64_t>(c) * TL + tl;
+        float v[VEC], m[VEC];
+        E::unpack(SINGLE ? keep : xg[off], v);
+#pragma unroll
+        for (int i = 0; i < VEC; i += 4) {
+          const float4 m4 = *reinterpret_cast<const float4*>(cs + off * VEC + i);
+          m[i] = m4.x, m[i + 1] = m4.y, m[i + 2] = m4.z, m[i + 3] = m4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float xs = sp.divide_first ? v[i] / m[i] : v[i] * m[i];
+          if (ZD == DCQ_ZERO_NONE) {
+            mx = fmaxf(mx, fabsf(xs));
+          } else {
+            mx = fmaxf(mx, xs);
+            mn = fminf(mn, xs);
+          }
+        }
+      }
+      const float local_abs = ZD == DCQ_ZERO_NONE ? mx : fmaxf(fabsf(mx), fabsf(mn));
+      float vmax = team_reduce<true>(mx, TL), vmin = 0.0f;
+      if (ZD != DCQ_ZERO_NONE) vmin = team_reduce<false>(mn, TL);
+      if (p.has_ratio) {
+        vmax = vmax * p.ratio;
+        if (ZD != DCQ_ZERO_NONE) vmin = vmin * p.ratio;
+      }
+      if (ZD == DCQ_ZERO_PRE_SCALE) {
+        vmax = fmaxf(vmax, 0.0f);
+        vmin = fminf(vmin, 0.0f);
+      }
+      if (p.has_bound_max) vmax = fminf(vmax, p.bound_max);
+      if (ZD != DCQ_ZERO_NONE && p.has_bound_min) vmin = fmaxf(vmin, p.bound_min);
+      const float span = ZD != DCQ_ZERO_NONE ? vmax - vmin : vmax;
+      float sc = round_scale<SK>(fabsf(span / p.q_span));
+      if (sc == 0.0f) sc = 1.0f;
+      float ze = 0.0f;
+      if (ZD == DCQ_ZERO_PRE_SCALE) ze = fminf(fmaxf(rintf(p.q_min - vmin / sc), p.z_lo), p.z_hi);
+      if (ZD == DCQ_ZERO_POST_SCALE) ze = round_scale<SK>(p.q_min * sc - vmin);
+      const Divisor dv = make_divisor(sc, local_abs + fabsf(ze));
+      // ---- pass 2: quantize, dequantize, take the smoothing back, cast
+      float acc = 0.0f;
+      for (int c = 0; c < chunks; ++c) {
+        const int64_t off = static_cast<int64_t>(c) * TL + tl;
+        float v[VEC], m[VEC], o[VEC];
+        E::unpack(SINGLE ? keep : xg[off], v);
+#pragma unroll
+        for (int i = 0; i < VEC; i += 4) {
+          const float4 m4 = *reinterpret_cast<const float4*>(cs + off * VEC + i);
+          m[i] = m4.x, m[i + 1] = m4.y, m[i + 2] = m4.z, m[i + 3] = m4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float xs = sp.divide_first ? v[i] / m[i] : v[i] * m[i];
+          float a = xs;
+          if (ZD == DCQ_ZERO_POST_SCALE) a = a + ze;
+          float t = dv.fast ? div_fast(a, dv) : a / sc;
+          if (ZD == DCQ_ZERO_PRE_SCALE) t = t + ze;
+          const float q = clamp_f(rintf(t), p.q_lo, p.q_hi);
+          const float d = from_code<ZD>(q, sc, ze);
+          o[i] = sp.divide_first ? d * m[i] : d / m[i];
+        }
+        if (sp.errors) {
+          const raw_t packed = E::pack(o);  // rounds to the storage type exactly as the written tensor would be
+          float r[VEC];
+          E::unpack(packed, r);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc = acc + error_term<ST>(r[i], v[i], sp);
+        } else if (live) {
+          out[g * raws_per_group + off] = E::pack(o);
+        }
+      }
+      if (sp.errors) {
+        for (int w = TL >> 1; w > 0; w >>= 1) acc = acc + __shfl_xor(acc, w, kWave);
+        if (tl == 0 && live) sp.errors[static_cast<int64_t>(k) * p.G + g] = acc;
+      }
+    }
+  }
+}
+
+template <int ST, int ZD, int SK>
+static int launch_smooth(const SmoothParams& sp, hipStream_t stream) {
+  const int64_t threads = sp.f.G * sp.f.team_lanes;
+  int64_t blocks = (threads + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (sp.f.chunks == 1) {
+    hipLaunchKernelGGL((smooth_int_kernel<ST, ZD, SK, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sp);
+  } else {
+    hipLaunchKernelGGL((smooth_int_kernel<ST, ZD, SK, false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sp);
+  }
+  DCQ_LAUNCH_CHECK("smooth_int_kernel launch");
+  return DCQ_OK;
+}
+
+template <int ST, int ZD>
+static int smooth_scale_kind(const SmoothParams& sp, int sk, hipStream_t stream) {
+  switch (sk) {
+    case DCQ_ROUND_F16:
+      return launch_smooth<ST, ZD, DCQ_ROUND_F16>(sp, stream);
+    case DCQ_ROUND_BF16:
+      return launch_smooth<ST, ZD, DCQ_ROUND_BF16>(sp, stream);
+    default:
+      return launch_smooth<ST, ZD, DCQ_ROUND_F32>(sp, stream);
+  }
+}
+
+template <int ST>
+static int smooth_zero(const SmoothParams& sp, int zd, int sk, hipStream_t stream) {
+  switch (zd) {
+    case DCQ_ZERO_NONE:
+      return smooth_scale_kind<ST, DCQ_ZERO_NONE>(sp, sk, stream);
+    case DCQ_ZERO_PRE_SCALE:
+      return smooth_scale_kind<ST, DCQ_ZERO_PRE_SCALE>(sp, sk, stream);
+    default:
+      return smooth_scale_kind<ST, DCQ_ZERO_POST_SCALE>(sp, sk, stream);
+  }
+}
+
 __global__ void selftest_division_kernel(const float* x, const float* sv, float* fast, float* ref, int* used_fast,
                                          int64_t n) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -388,4 +570,79 @@ extern "C" int dcq_selftest_division(const float* x, const float* s, float* fast
                      static_cast<hipStream_t>(stream), x, s, fast, ref, used_fast, n);
   DCQ_LAUNCH_CHECK("selftest_division_kernel launch");
   return DCQ_OK;
+}
+
+extern "C" int dcq_smooth_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
+                                            int64_t groups_per_row, const float* chan_scale, int32_t K, int32_t mode,
+                                            int32_t has_ratio, float ratio, void* dequant, float* errors, double degree,
+                                            const uint16_t* pow_table, dcq_stream_t stream) {
+  using namespace dcq;
+  DCQ_REQUIRE(step != nullptr, DCQ_ERR_ARGUMENT, "step is NULL");
+  DCQ_REQUIRE(G >= 0 && S > 0 && groups_per_row > 0 && K > 0, DCQ_ERR_ARGUMENT, "bad sizes");
+  DCQ_REQUIRE(mode == 0 || mode == 1, DCQ_ERR_ARGUMENT, "mode must be 0 (multiply first) or 1 (divide first)");
+  DCQ_REQUIRE((dequant != nullptr) != (errors != nullptr), DCQ_ERR_ARGUMENT,
+              "exactly one of the processed tensor and the error table is written");
+  DCQ_REQUIRE(dequant == nullptr || K == 1, DCQ_ERR_ARGUMENT, "the processed tensor is written for one candidate");
+  if (G == 0) return DCQ_OK;
+  DCQ_REQUIRE(x && chan_scale, DCQ_ERR_ARGUMENT, "NULL buffer");
+  const dcq_step& st = *step;
+  const int sk = st.scale.kind;
+  const bool scale_ok = (sk == DCQ_ROUND_F32 || sk == DCQ_ROUND_F16 || sk == DCQ_ROUND_BF16) && !st.scale.has_clamp;
+  bool zero_ok = true;
+  if (st.zero_domain == DCQ_ZERO_PRE_SCALE) zero_ok = st.zero.kind == DCQ_ROUND_INT;
+  if (st.zero_domain == DCQ_ZERO_POST_SCALE) zero_ok = st.zero.kind == sk && !st.zero.has_clamp;
+  DCQ_REQUIRE(st.tensor.kind == DCQ_ROUND_INT && scale_ok && zero_ok, DCQ_ERR_UNSUPPORTED,
+              "the fused smoothing kernel takes integer types with one float scale level");
+  const int vec = storage == DCQ_F32 ? 4 : 8;
+  auto aligned = [](const void* ptr, uintptr_t a) { return ptr == nullptr || (reinterpret_cast<uintptr_t>(ptr) % a) == 0; };
+  DCQ_REQUIRE(S % vec == 0 && S <= (1 << 30) && aligned(x, 16) && aligned(dequant, 16) && aligned(chan_scale, 16),
+              DCQ_ERR_UNSUPPORTED, "groups must be whole 16-byte pieces of 16-byte aligned buffers");
+  const int64_t n = S / vec;
+  int lanes = 1;
+  while (lanes < 64 && n % (lanes * 2) == 0) lanes *= 2;
+  SmoothParams sp{};
+  FusedParams& p = sp.f;
+  p.x = x;
+  p.dequant = dequant;
+  p.G = G;
+  p.S = static_cast<int32_t>(S);
+  p.team_lanes = lanes;
+  p.team_shift = __builtin_ctz(static_cast<unsigned>(lanes));
+  p.chunks = static_cast<int32_t>(n / lanes);
+  p.has_ratio = has_ratio;
+  p.ratio = ratio;
+  p.q_lo = st.tensor.lo;
+  p.q_hi = st.tensor.hi;
+  p.z_lo = st.zero.lo;
+  p.z_hi = st.zero.hi;
+  p.q_span = st.q_span;
+  p.q_min = st.q_min;
+  p.has_bound_min = st.has_bound_min;
+  p.has_bound_max = st.has_bound_max;
+  p.bound_min = st.bound_min;
+  p.bound_max = st.bound_max;
+  sp.chan_scale = chan_scale;
+  sp.groups_per_row = static_cast<int32_t>(groups_per_row);
+  sp.C = groups_per_row * S;
+  sp.divide_first = mode;
+  sp.K = K;
+  sp.errors = errors;
+  sp.degree = static_cast<float>(degree);
+  sp.table = nullptr;
+  if (errors != nullptr && storage != DCQ_F32 && round_degree_to_storage(degree, storage) != 2.0) {
+    DCQ_REQUIRE(pow_table != nullptr, DCQ_ERR_ARGUMENT, "pow_table is NULL (build it with dcq_pow_table)");
+    sp.table = pow_table;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (storage) {
+    case DCQ_F32:
+      return smooth_zero<DCQ_F32>(sp, st.zero_domain, sk, s);
+    case DCQ_F16:
+      return smooth_zero<DCQ_F16>(sp, st.zero_domain, sk, s);
+    case DCQ_BF16:
+      return smooth_zero<DCQ_BF16>(sp, st.zero_domain, sk, s);
+    default:
+      set_error("bad storage %d", storage);
+      return DCQ_ERR_ARGUMENT;
+  }
 }

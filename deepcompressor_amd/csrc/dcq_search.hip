@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void group_error_kernel(const GroupErrorParams
   }
 }
 
-static double round_degree_to_storage(double degree, int storage) {
+double round_degree_to_storage(double degree, int storage) {
   // float -> storage -> double, on the host (bit manipulation; no fp16 hardware assumed)
   const float f = static_cast<float>(degree);
   uint32_t u;

@@ -305,6 +305,45 @@ def range_search_groups(step: Step, w: torch.Tensor, ratios: list[float], degree
     return out
 
 
+def smooth_step_is_fusable(step: Step) -> bool:
+    """Whether ``dcq_smooth_fake_quant_groups`` covers this step: an integer type with one float scale level."""
+    floats = (_lib.ROUND_F32, _lib.ROUND_F16, _lib.ROUND_BF16)
+    if step.tensor.kind != _lib.ROUND_INT or step.scale.kind not in floats or step.scale.has_clamp:
+        return False
+    if step.zero_domain == _lib.ZERO_PRE:
+        return step.zero.kind == _lib.ROUND_INT
+    if step.zero_domain == _lib.ZERO_POST:
+        return step.zero.kind == step.scale.kind and not step.zero.has_clamp
+    return True
+
+
+def smooth_fake_quant(step: Step, x: torch.Tensor, groups_per_row: int, chan_scale: torch.Tensor, *,
+                      divide_first: bool, ratio: float | None = None, errors_degree: float | None = None
+                      ) -> torch.Tensor:
+    """x[G][S] (groups along the channels) and chan_scale [C] or [K][C] float32 -> the smoothed, fake-quantized,
+    un-smoothed tensor in x's dtype (one candidate), or with ``errors_degree`` the float32 [K][G] sums of
+    |processed - x|^degree of every candidate, evaluated in x's dtype."""
+    _require_gpu(x)
+    assert x.ndim == 2 and x.is_contiguous()
+    G, S = x.shape
+    cs = chan_scale.to(device=x.device, dtype=torch.float32).contiguous().view(-1, groups_per_row * S)
+    K = cs.shape[0]
+    out = errors = table = None
+    degree = 0.0
+    if errors_degree is None:
+        assert K == 1, "one candidate when the processed tensor is wanted"
+        out = torch.empty_like(x)
+    else:
+        degree = float(errors_degree)
+        errors = torch.empty((K, G), dtype=torch.float32, device=x.device)
+        table = pow_table(x.device, x.dtype, degree) if x.dtype != torch.float32 else None
+    check(lib().dcq_smooth_fake_quant_groups(C.byref(step), ptr(x), storage_of(x.dtype), G, S, groups_per_row, ptr(cs), K,
+                                             1 if divide_first else 0, 0 if ratio is None else 1,
+                                             0.0 if ratio is None else float(ratio), ptr(out), ptr(errors), degree,
+                                             ptr(table), stream_of(x.device)), "dcq_smooth_fake_quant_groups")
+    return out if errors is None else errors
+
+
 def group_error(a: torch.Tensor, b: torch.Tensor, degree: float) -> torch.Tensor:
     """a, b [G][S] of one dtype -> float32 [G]: sum over each group of |a - b|^degree evaluated in that dtype,
     accumulated in float32 and not rounded back."""

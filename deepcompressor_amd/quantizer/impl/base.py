@@ -224,6 +224,57 @@ class QuantizerImpl:
                            scale=quant_scale if want_quant else None, zero=step_zero if want_quant else None,
                            view_shape=view if want_quant else None)
 
+    def smooth_candidates(self, tensor: torch.Tensor, chan_scale: torch.Tensor, *, divide_first: bool,
+                          channels_dim: int | None = None, scale=None, zero=None, dynamic_range=None,
+                          range_bound: RangeBound | None = None, quant_range: QuantRange | None = None,
+                          default_dtype: torch.dtype | None = None, errors_degree: float | None = None
+                          ) -> torch.Tensor | None:
+        """A smoothing candidate through the fused kernel (reference op chain: calib/smooth.py:504-530).
+
+        ``chan_scale`` [C]: returns ``Q(tensor * s) / s`` (or ``Q(tensor / s) * s`` with ``divide_first``) in the
+        tensor's dtype, equal bit for bit to scaling in float32, ``quantize`` and scaling back.  ``chan_scale``
+        [K][C] with ``errors_degree``: returns the float32 [K][#groups] error sums |processed - tensor|^degree of all
+        K candidates from one read of the tensor.  Returns None when the configuration is outside the fused kernel
+        (several steps or scale levels, non-integer types, fixed scales or ranges, groups that are not runs of
+        channels inside one row): the caller then takes the general path."""
+        if not tensor.is_cuda or not tensor.is_contiguous():
+            return None
+        shape = tensor.shape
+        if channels_dim is not None:
+            tensor = tensor.reshape(-1, *shape[channels_dim:])
+        if tensor.ndim != 2 or scale is not None or zero is not None:
+            return None
+        ratio = None
+        if isinstance(dynamic_range, (tuple, list)):
+            dynamic_range = dynamic_range[0] if len(dynamic_range) == 1 else "several"
+        if dynamic_range is not None:
+            if not isinstance(dynamic_range, DynamicRange):
+                return None
+            if dynamic_range.is_set():
+                if dynamic_range.max is not None or isinstance(dynamic_range.ratio, torch.Tensor):
+                    return None
+                ratio = dynamic_range.ratio
+        info = self.update(tensor.shape, default_dtype or tensor.dtype, quant_range, range_bound)
+        if info is None or info.num_steps != 1:
+            return None
+        last = info.steps[-1]
+        view = last.tensor_view_shape
+        if not last.scale.is_single_level() or len(view) != 4 or view[1] != 1:
+            return None
+        if last.scale.has_zero_point and last.quant_dtype.is_float_point:
+            return None
+        step = last.scale.native(tensor.device)
+        if not engine.smooth_step_is_fusable(step):
+            return None
+        rows, _, groups_per_row, group = view
+        vec = 4 if tensor.dtype == torch.float32 else 8
+        if group % vec or chan_scale.shape[-1] != groups_per_row * group or tensor.data_ptr() % 16:
+            return None
+        x2d = tensor.view(rows * groups_per_row, group)
+        out = engine.smooth_fake_quant(step, x2d, groups_per_row, chan_scale, divide_first=divide_first, ratio=ratio,
+                                       errors_degree=errors_degree)
+        return out.view(shape) if errors_degree is None else out
+
     def update(self, tensor_shape: torch.Size, default_dtype: torch.dtype | None, quant_range: QuantRange | None,
                range_bound: RangeBound | None) -> QuantInfo | None:
         """(Re)build the plan when the config, shape, default dtype or ranges changed."""

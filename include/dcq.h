@@ -327,6 +327,23 @@ int dcq_gemm_f64(const void* A, int32_t a_storage, int64_t lda, int32_t a_kmajor
  * (smooth_upscale_param), `narrow(dim, 0, scale.numel()).div_(scale)` (smooth_downscale_param) and
  * ActivationSmoother.process.  x and y may be the same buffer when the storage types match.
  * ------------------------------------------------------------------------------------------- */
+/* dcq_smooth_fake_quant_groups: one smoothing candidate applied to a tensor in ONE pass (calib/smooth.py:504-530), or
+ * the TensorError of K candidates from one read of the tensor (calib/search.py:776-790 with the candidate processing of
+ * smooth.py:519-530).  x[G][S] holds groups that run along the channel dimension: element i of group g is channel
+ * (g % groups_per_row) * S + i; chan_scale[K][C] with C = groups_per_row * S.
+ *   mode 0 (weights):      y = storage(Q(float32(x) * s) / s)        `w.mul(s)` -> quantize -> `.div(s)` -> cast
+ *   mode 1 (activations):  y = storage(Q(float32(x) / s) * s)        ActivationSmoother + quantizer + un-smoothing
+ * Q is the single-step, single-scale-level integer fake quantization of `step` on the float32 values with a dynamic
+ * per-group range (times `ratio` when has_ratio), exactly as dcq_fake_quant_groups computes it.
+ *   dequant != NULL (K must be 1): y is written in the layout and storage type of x.
+ *   errors  != NULL: errors[k][g] = sum_i pow(|y_k - x|, degree), difference, magnitude and power each rounded to the
+ *                    storage type, the sum in float32 and left unrounded (as dcq_group_error); nothing else is written.
+ * Exactly one of dequant / errors is given.  DCQ_ERR_UNSUPPORTED for step types the fused kernel does not cover. */
+int dcq_smooth_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
+                                 int64_t groups_per_row, const float* chan_scale, int32_t K, int32_t mode,
+                                 int32_t has_ratio, float ratio, void* dequant, float* errors, double degree,
+                                 const uint16_t* pow_table, dcq_stream_t stream);
+
 int dcq_channel_metric(const void* x, int32_t storage, int64_t N, int64_t C, int64_t inner, int32_t mode, float* out_max,
                        double* out_sum, dcq_stream_t stream);
 
