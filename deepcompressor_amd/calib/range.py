@@ -274,7 +274,9 @@ class DynamicRangeCalibrator:
     def _products_scorer(self, w: torch.Tensor, x_acts: TensorsCache, orig_x_wgts, orig_x_acts):
         """ProductsError (calib/search.py:697-745, 791-816).  Per input batch x[n, C] the reference multiplies every
         quantization group on its own, y[r, cg, n] = sum_i x[n, cg*g + i] * w[r, cg*g + i], in the weight's dtype
-        (a broadcast matmul over (R, C/g) tiny products); here that is one batched GEMM over the C/g column groups.
+        (a broadcast matmul over (R, C/g) tiny products); here that is one batched GEMM over the C/g column groups,
+        accumulated in float64 and rounded once (``engine.grouped_products``): a product does not depend on any
+        backend's float32 summation order.
         Error per (r, cg) = sum_n float32(dtype(y - y0))^degree, batches added up in float32."""
         view = self.view_shape
         if len(view) != 4 or view[1] != 1:
@@ -288,7 +290,7 @@ class DynamicRangeCalibrator:
             return x.to(device=dev, dtype=dt).view(-1, CG, g).permute(1, 2, 0).contiguous()
 
         def products(xg: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:  # -> [CG * R, n]
-            return torch.bmm(weight.view(R, CG, g).transpose(0, 1), xg).view(CG * R, -1)
+            return engine.grouped_products(weight.view(R, CG * g), xg, dt).view(CG * R, -1)
 
         batches = [grouped(ipts.front().reshape(x)) for x in ipts.front().data]
         orig_w = orig_x_wgts[0][1].to(dev) if orig_x_wgts is not None else w
@@ -506,13 +508,18 @@ class DynamicRangeCalibrator:
         assert len(originals) == len(weights)
         assert all(w.ndim == 2 for w in weights), "ProductsError for inputs takes the weights of linear modules"
 
-        def products(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        def k_major(w: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+            """[R, C] -> [groups, g, R] in the inputs' dtype: the right-hand operand of x[:, group] @ w[:, group]^T."""
+            w = w.to(like.dtype)
             if layer:
-                return torch.matmul(x, w.t()).view(1, -1)
-            xg = x.view(-1, CG, g).transpose(0, 1)  # [CG, n, g]
-            wg = w.view(w.shape[0], CG, g).permute(1, 2, 0)  # [CG, g, R]
-            return torch.bmm(xg, wg.to(x.dtype)).view(CG, -1)
+                return w.t().contiguous().view(1, w.shape[1], w.shape[0])
+            return w.view(w.shape[0], CG, g).permute(1, 2, 0).contiguous()
 
+        def products(x: torch.Tensor, wk: torch.Tensor) -> torch.Tensor:  # float64 accumulation, rounded once
+            return engine.grouped_products(x, wk, x.dtype).view(1 if layer else CG, -1)
+
+        weights = [k_major(w, batches[0]) for w in weights]
+        originals = [k_major(w, orig_batches[0]) for w in originals]
         base = [[products(x, w) for x in orig_batches] for w in originals]
 
         def score(candidate: DynamicRange) -> torch.Tensor:

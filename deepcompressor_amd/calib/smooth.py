@@ -588,11 +588,13 @@ class SmoothCalibrator:
         def products(x: torch.Tensor, w: torch.Tensor, view) -> torch.Tensor:
             """x [n, C] and w [R, C] -> [n, R] (Layer) or [CG * R, n] (partial products per channel group)."""
             x = cache.reshape(x).view(x.shape[0], -1).to(device=dev, dtype=dt)
+            # float64 accumulation, rounded once (engine.grouped_products): no float32 summation order to depend on
             if layer:
-                return torch.matmul(x, w.view(w.shape[0], -1).t()).contiguous()
+                wk = w.view(w.shape[0], -1).t().contiguous()
+                return engine.grouped_products(x, wk.view(1, *wk.shape), dt).view(x.shape[0], -1)
             R, _, CG, g = view
-            xg = x.view(-1, CG, g).permute(1, 2, 0)
-            return torch.bmm(w.view(R, CG, g).transpose(0, 1), xg).view(CG * R, -1)
+            xg = x.view(-1, CG, g).permute(1, 2, 0).contiguous()
+            return engine.grouped_products(w.view(R, CG * g), xg, dt).view(CG * R, -1)
 
         orig_cache = cache if orig_ipts is None else orig_ipts.front()
         base = [[products(x, w, view) for x in orig_cache.data] for w, view in zip(origs, views)]

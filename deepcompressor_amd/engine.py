@@ -305,6 +305,28 @@ def range_search_groups(step: Step, w: torch.Tensor, ratios: list[float], degree
     return out
 
 
+def grouped_products(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype | None = None) -> torch.Tensor:
+    """a [M][B * K] (row-major), b [B][K][N] -> out [B][M][N] with out[g] = a[:, g * K : (g + 1) * K] @ b[g]: the
+    partial products of every group of K columns (B = 1: a plain product).  Accumulated in float64 on the matrix
+    cores and rounded double -> float32 -> dtype once (``dcq_gemm_f64``), so each product is the correctly rounded
+    float32 sum, cast like ``Tensor.to`` -- whatever order a float32-accumulating GEMM would have used, and
+    reproducible on any machine."""
+    _require_gpu(a)
+    assert a.ndim == 2 and b.ndim == 3 and a.stride(1) == 1 and b.is_contiguous() and a.device == b.device
+    groups, K, N = b.shape
+    M = a.shape[0]
+    assert a.shape[1] == groups * K, f"{tuple(a.shape)} does not split into {groups} groups of {K} columns"
+    out_dtype = out_dtype or a.dtype
+    out = torch.empty((groups, M, N), dtype=out_dtype, device=a.device)
+    if out.numel() == 0:
+        return out
+    storage = {torch.float64: 3, torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+    raw = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    check(lib().dcq_gemm_f64(raw(a), storage[a.dtype], a.stride(0), 0, K, raw(b), storage[b.dtype], N, K * N, raw(out),
+                             storage[out_dtype], N, M * N, M, N, K, groups, stream_of(a.device)), "dcq_gemm_f64")
+    return out
+
+
 def smooth_step_is_fusable(step: Step) -> bool:
     """Whether ``dcq_smooth_fake_quant_groups`` covers this step: an integer type with one float scale level."""
     floats = (_lib.ROUND_F32, _lib.ROUND_F16, _lib.ROUND_BF16)

@@ -26,6 +26,30 @@ def run_oracle(tag):
                                        element_batch_size=m["element_batch_size"])
 
 
+def clear_winner(m, tag, want_err) -> np.ndarray:
+    """Per searched group: do the reference's two best candidates differ by more than one product landing on the
+    neighbouring value of the 16-bit type can change a group's error?  With u the spacing of the type at the group's
+    largest product and d = (second-best error)^(1/degree) a bound on any single difference, that change is at most
+    (d + u)^degree - d^degree."""
+    w = RP[f"{tag}|w"].astype(np.float64)
+    bits = {"bf16": 7, "f16": 10}[m["in_dtype"]]
+    errs = want_err.reshape(want_err.shape[0], -1)
+    groups = errs.shape[1]
+    xs = np.concatenate([RP[f"{tag}|x{i}"].reshape(-1, w.shape[1]) for i in range(2)]).astype(np.float64)
+    if m["resolved_objective"] == "ProductsError" and groups > 1:
+        cg = groups // w.shape[0] if m["resolved_granularity"] == "Group" else groups
+        g = w.shape[1] // cg
+        y = np.einsum("ncg,rcg->rcn", xs.reshape(-1, cg, g), w.reshape(w.shape[0], cg, g))
+        top = np.abs(y).max(axis=2) if m["resolved_granularity"] == "Group" else np.abs(y).max(axis=(0, 2))
+        top = top.reshape(-1)
+    else:
+        top = np.full(groups, np.abs(xs @ w.T).max())
+    spacing = 2.0 ** (np.floor(np.log2(np.maximum(top, 1e-30))) - bits)
+    srt = np.sort(errs, axis=0)
+    d = srt[1] ** (1.0 / m["degree"])
+    return (srt[1] - srt[0]) > ((d + spacing) ** m["degree"] - d ** m["degree"])
+
+
 def check_against_fixture(m, tag, errors, ratio, vmax):
     want_err = RP[f"{tag}|s0|errors"].reshape(np.asarray(errors).shape)
     want_ratio = RP[f"{tag}|s0|ratio"].reshape(ratio.shape)
@@ -40,14 +64,20 @@ def check_against_fixture(m, tag, errors, ratio, vmax):
         if same.all():
             np.testing.assert_array_equal(vmax, RP[f"{tag}|s0|max"])
         return
-    # 16-bit products: most entries agree closely, the totals per candidate agree, most winners agree
+    # 16-bit products.  The reference's GEMM rounds each product to the 16-bit type after a float32 sum in an order of
+    # its backend's choosing; here every product is the correctly rounded sum.  The two can differ by one unit in the
+    # last place of a product, so: most entries agree closely, the totals per candidate agree, and the winner is the
+    # reference's wherever its best two candidates are further apart than ONE product moving by one unit can explain.
     rel = np.abs(errors - want_err) / np.maximum(want_err, 1e-30)
     assert np.median(rel) < 2e-2
     np.testing.assert_allclose(errors.reshape(errors.shape[0], -1).sum(1), want_err.reshape(errors.shape[0], -1).sum(1),
                                rtol=3e-2)
     if ratio.size > 1:
-        assert (ratio.reshape(-1) == want_ratio.reshape(-1)).mean() > 0.6
+        clear = clear_winner(m, tag, want_err)
+        same = ratio.reshape(-1) == want_ratio.reshape(-1)
+        assert same[clear].all(), (int(clear.sum()), int((~same[clear]).sum()))
         assert np.abs(ratio.reshape(-1) - want_ratio.reshape(-1)).mean() < 0.05
+        return float(clear.mean())
 
 
 @pytest.mark.parametrize("tag", sorted(t for t, m in RP.meta.items() if m["reference_raised"] is None))
