@@ -51,6 +51,14 @@ struct GroupParams {
   const float* scale_in;
   const float* zero_in;
   const float* round_delta;  // [G][S]: codes = clamp(floor(t) + delta) instead of round-to-nearest, or NULL
+  // two scale levels, the first one per tensor (NVFP4-style): the largest un-quantized group scale of the whole
+  // tensor (device scalar, produced by tensor_absmax_kernel), the first level's rounding and span; the second level
+  // is step.scale.  Outputs: level0_out[1], level1_out[G] (scale_out then receives the compound).
+  const float* tensor_absmax;
+  dcq_rounding level0;
+  float level0_span;
+  float* level0_out;
+  float* level1_out;
   // previous progressive step
   const float* outer;
   float outer_lo, outer_hi;
@@ -151,9 +159,29 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
         if (ZD != DCQ_ZERO_NONE) vmin = p.range_min[g];
         if (SINGLE) keep = load_chunk<in_t, VEC>(xg + static_cast<int64_t>(tl) * VEC);
       }
-      const ScaleZero sz = scale_zero_from_range(st, vmax, vmin, cbs.v[1], cbs.v[2]);
-      s = sz.s;
-      z = sz.z;
+      if (p.tensor_absmax) {
+        // quantize_scale with two levels (quantizer/impl/scale.py:46-62): the first level quantizes the tensor's
+        // largest group scale over the second level's span, the second level each group's scale relative to it.
+        // Division by q_span is monotone, so the largest group scale is the scale of the largest magnitude.
+        float top = *p.tensor_absmax;
+        if (p.has_ratio) top = top * p.ratio;
+        if (st.has_bound_max) {
+          top = fminf(top, st.bound_max);
+          vmax = fminf(vmax, st.bound_max);
+        }
+        const float level0 = apply_rounding(p.level0, fabsf(top / st.q_span) / p.level0_span, nullptr);
+        const float level1 = apply_rounding(st.scale, fabsf(vmax / st.q_span) / level0, cbs.v[1]);
+        s = level1 * level0;
+        if (s == 0.0f) s = 1.0f;
+        if (tl == 0) {
+          if (p.level1_out) p.level1_out[g] = level1;
+          if (g == 0 && p.level0_out) *p.level0_out = level0;
+        }
+      } else {
+        const ScaleZero sz = scale_zero_from_range(st, vmax, vmin, cbs.v[1], cbs.v[2]);
+        s = sz.s;
+        z = sz.z;
+      }
       if (tl == 0) {
         if (p.scale_out) p.scale_out[g] = s;
         if (p.zero_out) p.zero_out[g] = z;
@@ -461,6 +489,34 @@ __global__ __launch_bounds__(kBlock) void prescale_kernel(const typename Storage
   }
 }
 
+// max |x| over a whole tensor into *out (which the caller has zeroed): non-negative floats order like their bit
+// patterns, so the workgroups' maxima meet in one integer atomic; any order gives the same bits.
+template <int ST>
+__global__ __launch_bounds__(kBlock) void tensor_absmax_kernel(const typename Storage<ST>::elem_t* x, int64_t n,
+                                                               float* out) {
+  using elem_t = typename Storage<ST>::elem_t;
+  constexpr int VEC = Storage<ST>::kVec;
+  __shared__ float red[kBlock / kWave];
+  float m = 0.0f;
+  const int64_t chunks = n / VEC;
+  for (int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; c < chunks;
+       c += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const Chunk<elem_t, VEC> ch = load_chunk<elem_t, VEC>(x + c * VEC);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) m = fmaxf(m, fabsf(Storage<ST>::load(ch.v[i])));
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = chunks * VEC + threadIdx.x; i < n; i += kBlock) m = fmaxf(m, fabsf(Storage<ST>::load(x[i])));
+  m = team_max(m, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; ++w) m = fmaxf(m, red[w]);
+    atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  }
+}
+
 static unsigned small_grid(int64_t n) {
   int64_t b = (n + kBlock - 1) / kBlock;
   if (b > 2048) b = 2048;
@@ -525,11 +581,9 @@ int dcq_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, 
               "a static range with a zero point needs range_min");
   DCQ_REQUIRE(!(range_max && has_ratio), DCQ_ERR_UNSUPPORTED,
               "ratio together with a bounding range: use dcq_group_range + dcq_range_to_scale");
-  if (getenv("DCQ_NO_LEAN_KERNEL") == nullptr) {
-    rc = try_launch_fused_int(*step, x, storage, G, S, range_max, range_min, has_ratio, ratio, dequant, codes, scale,
-                              zero, static_cast<hipStream_t>(stream));
-    if (rc != DCQ_ERR_UNSUPPORTED) return rc;
-  }
+  rc = try_launch_fused_int(*step, x, storage, G, S, range_max, range_min, has_ratio, ratio, dequant, codes, scale,
+                            zero, static_cast<hipStream_t>(stream));
+  if (rc != DCQ_ERR_UNSUPPORTED) return rc;
   GroupParams p{};
   p.step = *step;
   p.x = x;
@@ -544,6 +598,98 @@ int dcq_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, 
   p.scale_out = scale;
   p.zero_out = zero;
   return dispatch_storage<kFused>(p, storage, storage, static_cast<hipStream_t>(stream));
+}
+
+int dcq_fake_quant_groups_outer(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
+                                const float* outer, float outer_lo, float outer_hi, int32_t deq_clamp, float deq_lo,
+                                float deq_hi, const float* range_max, const float* range_min, int32_t has_ratio,
+                                float ratio, void* dequant, int32_t out_storage, float* codes, float* scale, float* zero,
+                                dcq_stream_t stream) {
+  int rc = validate_step(step);
+  if (rc != DCQ_OK) return rc;
+  DCQ_REQUIRE(G >= 0 && S >= 0, DCQ_ERR_ARGUMENT, "negative size");
+  if (G == 0 || S == 0) return DCQ_OK;
+  DCQ_REQUIRE(x && outer, DCQ_ERR_ARGUMENT, "NULL buffer");
+  DCQ_REQUIRE(storage >= DCQ_F32 && storage <= DCQ_BF16, DCQ_ERR_ARGUMENT, "bad storage %d", storage);
+  DCQ_REQUIRE(!needs_mean_centred_range(step), DCQ_ERR_UNSUPPORTED,
+              "floating-point dtype with a zero point after a progressive step");
+  DCQ_REQUIRE(!(range_max && step->zero_domain != DCQ_ZERO_NONE && !range_min), DCQ_ERR_ARGUMENT,
+              "a static range with a zero point needs range_min");
+  DCQ_REQUIRE(!(range_max && has_ratio), DCQ_ERR_UNSUPPORTED, "ratio together with a static range");
+  GroupParams p{};
+  p.step = *step;
+  p.x = x;
+  p.G = G;
+  p.S = S;
+  p.range_max = range_max;
+  p.range_min = range_min;
+  p.has_ratio = has_ratio;
+  p.ratio = ratio;
+  p.outer = outer;
+  p.outer_lo = outer_lo;
+  p.outer_hi = outer_hi;
+  p.deq_clamp = deq_clamp;
+  p.deq_lo = deq_lo;
+  p.deq_hi = deq_hi;
+  p.dequant = dequant;
+  p.codes = codes;
+  p.scale_out = scale;
+  p.zero_out = zero;
+  return dispatch_storage<kFused>(p, storage, dequant ? out_storage : storage, static_cast<hipStream_t>(stream));
+}
+
+int dcq_fake_quant_groups_two_level(const dcq_step* step, const dcq_rounding* level0, float level0_span, const void* x,
+                                    int32_t storage, int64_t G, int64_t S, int32_t has_ratio, float ratio,
+                                    float* tensor_absmax, void* dequant, float* codes, float* level0_out,
+                                    float* level1_out, float* scale, dcq_stream_t stream) {
+  int rc = validate_step(step);
+  if (rc != DCQ_OK) return rc;
+  DCQ_REQUIRE(level0 != nullptr && level0_span > 0.0f, DCQ_ERR_ARGUMENT, "first scale level is missing");
+  DCQ_REQUIRE(level0->kind == DCQ_ROUND_F32 || level0->kind == DCQ_ROUND_F16 || level0->kind == DCQ_ROUND_BF16,
+              DCQ_ERR_UNSUPPORTED, "the per-tensor scale level must be a float type");
+  DCQ_REQUIRE(step->zero_domain == DCQ_ZERO_NONE, DCQ_ERR_UNSUPPORTED, "two scale levels with a zero point");
+  DCQ_REQUIRE(G >= 0 && S >= 0, DCQ_ERR_ARGUMENT, "negative size");
+  if (G == 0 || S == 0) return DCQ_OK;
+  DCQ_REQUIRE(x && tensor_absmax, DCQ_ERR_ARGUMENT, "NULL buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = hip_check(hipMemsetAsync(tensor_absmax, 0, 4, s), "hipMemsetAsync(tensor_absmax)");
+  if (rc != DCQ_OK) return rc;
+  const int64_t n = G * S;
+  const unsigned grid = small_grid(n / 8);
+  switch (storage) {
+    case DCQ_F32:
+      hipLaunchKernelGGL(tensor_absmax_kernel<DCQ_F32>, dim3(grid), dim3(kBlock), 0, s, static_cast<const float*>(x), n,
+                         tensor_absmax);
+      break;
+    case DCQ_F16:
+      hipLaunchKernelGGL(tensor_absmax_kernel<DCQ_F16>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint16_t*>(x), n,
+                         tensor_absmax);
+      break;
+    case DCQ_BF16:
+      hipLaunchKernelGGL(tensor_absmax_kernel<DCQ_BF16>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint16_t*>(x),
+                         n, tensor_absmax);
+      break;
+    default:
+      set_error("bad storage %d", storage);
+      return DCQ_ERR_ARGUMENT;
+  }
+  DCQ_LAUNCH_CHECK("tensor_absmax_kernel launch");
+  GroupParams p{};
+  p.step = *step;
+  p.x = x;
+  p.G = G;
+  p.S = S;
+  p.has_ratio = has_ratio;
+  p.ratio = ratio;
+  p.tensor_absmax = tensor_absmax;
+  p.level0 = *level0;
+  p.level0_span = level0_span;
+  p.level0_out = level0_out;
+  p.level1_out = level1_out;
+  p.dequant = dequant;
+  p.codes = codes;
+  p.scale_out = scale;
+  return dispatch_storage<kFused>(p, storage, storage, s);
 }
 
 int dcq_group_range(const void* x, int32_t storage, int64_t G, int64_t S, int32_t zero_domain, const float* outer,

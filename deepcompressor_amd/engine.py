@@ -140,6 +140,41 @@ def fake_quant_fused(step: Step, x: torch.Tensor, *, range_max=None, range_min=N
     return dq, codes, scale, zero
 
 
+def fake_quant_fused_outer(step: Step, x: torch.Tensor, outer: torch.Tensor, outer_lo: float, outer_hi: float, *,
+                           deq_clamp: bool, deq_lo: float, deq_hi: float, range_max=None, range_min=None, ratio=None,
+                           out_dtype=None, want_dequant=True, want_codes=False):
+    """Last step of a progressive quantizer in one pass: x[G][S], outer[G] (the previous steps' scale per group)
+    -> (dequant | None, codes | None, scale[G], zero[G])."""
+    _require_gpu(x)
+    G, S = x.shape
+    out_dtype = out_dtype or x.dtype
+    dq = torch.empty((G, S), dtype=out_dtype, device=x.device) if want_dequant else None
+    codes = torch.empty((G, S), dtype=torch.float32, device=x.device) if want_codes else None
+    scale, zero = _f32(G, x.device), _f32(G, x.device)
+    check(lib().dcq_fake_quant_groups_outer(C.byref(step), ptr(x), storage_of(x.dtype), G, S, ptr(outer), float(outer_lo),
+                                            float(outer_hi), int(deq_clamp), float(deq_lo), float(deq_hi),
+                                            ptr(range_max), ptr(range_min), int(ratio is not None), float(ratio or 0.0),
+                                            ptr(dq), storage_of(out_dtype), ptr(codes), ptr(scale), ptr(zero),
+                                            stream_of(x.device)), "dcq_fake_quant_groups_outer")
+    return dq, codes, scale, zero
+
+
+def fake_quant_two_level(step: Step, level0: Rounding, level0_span: float, x: torch.Tensor, *, ratio=None,
+                         want_dequant=True, want_codes=False):
+    """Two scale levels, the first per tensor: x[G][S] -> (dequant | None, codes | None, level0[1], level1[G],
+    compound scale[G])."""
+    _require_gpu(x)
+    G, S = x.shape
+    dq = torch.empty_like(x) if want_dequant else None
+    codes = torch.empty((G, S), dtype=torch.float32, device=x.device) if want_codes else None
+    top, first, second, scale = _f32(1, x.device), _f32(1, x.device), _f32(G, x.device), _f32(G, x.device)
+    check(lib().dcq_fake_quant_groups_two_level(C.byref(step), C.byref(level0), float(level0_span), ptr(x),
+                                                storage_of(x.dtype), G, S, int(ratio is not None), float(ratio or 0.0),
+                                                ptr(top), ptr(dq), ptr(codes), ptr(first), ptr(second), ptr(scale),
+                                                stream_of(x.device)), "dcq_fake_quant_groups_two_level")
+    return dq, codes, first, second, scale
+
+
 def group_range(x: torch.Tensor, *, with_min: bool, outer: torch.Tensor | None = None, outer_lo: float = 0.0,
                 outer_hi: float = 0.0):
     _require_gpu(x)

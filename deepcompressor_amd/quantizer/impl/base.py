@@ -113,6 +113,10 @@ class QuantizerImpl:
                             and (dr_last.max is not None or isinstance(dr_last.ratio, torch.Tensor))))
         if fusable:
             return self._quantize_fused(tensor, dr_last, return_with_dequant, return_with_quant)
+        ratio_only = dr_last is None or (dr_last.max is None and not isinstance(dr_last.ratio, torch.Tensor))
+        if (n_steps == 1 and native_rtn and round_delta is None and scale[0] is None and ratio_only
+                and last.scale.is_two_level_per_tensor() and engine.groups_are_contiguous(last.tensor_view_shape)):
+            return self._quantize_two_level(tensor, dr_last, return_with_dequant, return_with_quant)
         return self._quantize_general(tensor, kernel, scale, zero, dynamic_range, round_delta, return_with_dequant,
                                       return_with_quant, kwargs)
 
@@ -151,6 +155,35 @@ class QuantizerImpl:
                            scale=QuantScale().append(scale) if want_quant else None,
                            zero=zero, view_shape=view if want_quant else None)
 
+    # ---- two scale levels, the first per tensor (NVFP4) ----------------------------------------
+    def _quantize_two_level(self, tensor, dyn, want_dequant, want_quant) -> QuantTensor:
+        """One reduction (the tensor's largest magnitude) and one pass, instead of range -> two scale-level kernels
+        -> join -> quantize over separate per-group arrays."""
+        step_info = self.info.steps[-1]
+        sinfo = step_info.scale
+        view = step_info.tensor_view_shape
+        keep = [v if i % 2 == 0 else 1 for i, v in enumerate(view)]
+        device = tensor.device
+        step = sinfo.native(device)
+        level0 = engine.make_rounding(sinfo.linear_scale_quant_dtypes[0], has_zero_point=False, quant_range=None,
+                                      device=device)
+        x2d, restore = engine.canonical_groups(tensor, view)
+        ratio = None if dyn is None else dyn.ratio
+        dq, codes, first, second, compound = engine.fake_quant_two_level(
+            step, level0, sinfo.linear_scale_quant_spans[0], x2d, ratio=ratio, want_dequant=want_dequant,
+            want_codes=want_quant)
+        quantized = scale = zero = None
+        if want_quant:
+            scale = QuantScale().append(first.view([1] * len(view))).append(second.view(keep))
+            scale.data = compound.view(keep)  # (a zero compound is 1: data/scale.py:66-69)
+            zero = torch.tensor(0, dtype=torch.float32, device=device)
+            if want_dequant:  # the reference's qdata aliases its in-place float32 dequantization buffer
+                codes = engine.dequantize_groups(step, codes, compound, None)
+            quantized = restore(codes)
+        return QuantTensor(dequantized=restore(dq) if want_dequant else None, quantized=quantized,
+                           scale=QuantScale().append(scale) if want_quant else None, zero=zero,
+                           view_shape=view if want_quant else None)
+
     # ---- general path ------------------------------------------------------------------------
     def _quantize_general(self, tensor, kernel, scale, zero, dynamic_range, round_delta, want_dequant, want_quant,
                           kwargs) -> QuantTensor:
@@ -159,11 +192,18 @@ class QuantizerImpl:
         quant_scale = QuantScale()
         outer = outer_range = None  # previous step: per-group divisor (in the current step's group order) and clamp
         outer_scale_data = None
+        native_rtn = kernel is None or type(kernel) is QuantRtnKernel
         for i, step_info in enumerate(info.steps):
             sinfo = step_info.scale
             n_groups = sinfo.num_groups
             if outer_scale_data is not None:
                 outer = _per_group(outer_scale_data, step_info.tensor_view_shape, n_groups)
+            if i == n_steps - 1 and outer is not None and native_rtn and round_delta is None and scale[i] is None \
+                    and zero is None:
+                fused = self._quantize_last_step_fused(tensor, step_info, dynamic_range[i], outer, outer_range,
+                                                       quant_scale, want_dequant, want_quant)
+                if fused is not None:
+                    return fused
             step_scale, step_zero = sinfo.quantize(scale=scale[i], zero=None if i < n_steps - 1 else zero,
                                                    tensor=tensor, dynamic_range=dynamic_range[i], outer=outer,
                                                    outer_range=outer_range)
@@ -274,6 +314,52 @@ class QuantizerImpl:
         out = engine.smooth_fake_quant(step, x2d, groups_per_row, chan_scale, divide_first=divide_first, ratio=ratio,
                                        errors_degree=errors_degree)
         return out.view(shape) if errors_degree is None else out
+
+    def _quantize_last_step_fused(self, tensor, last, dyn, outer, outer_range, quant_scale, want_dequant,
+                                  want_quant) -> QuantTensor | None:
+        """The last step of a progressive quantizer in one pass over the tensor (``dcq_fake_quant_groups_outer``):
+        range of clamp(x / outer), scale and zero of any one-level dtype, codes, dequantization back through the
+        previous steps' scale.  None when the step needs the general path (several scale levels, a floating-point
+        type with a zero point, a ratio on top of a fixed range)."""
+        sinfo, view, info = last.scale, last.tensor_view_shape, self.info
+        if not sinfo.is_single_level() or (sinfo.has_zero_point and last.quant_dtype.is_float_point):
+            return None
+        device, dtype = tensor.device, tensor.dtype
+        keep = [v if i % 2 == 0 else 1 for i, v in enumerate(view)]
+        rmax = rmin = ratio = None
+        if dyn is not None and dyn.is_set():
+            if dyn.max is not None:
+                if dyn.ratio is not None:
+                    return None
+                fmt = lambda v: DynamicRange._format_m_(  # noqa: E731
+                    v, shape=torch.Size(keep), dtype=torch.float32, device=device).contiguous().view(-1)
+                rmax = fmt(dyn.max)
+                rmin = fmt(dyn.min) if sinfo.has_zero_point else None
+            elif isinstance(dyn.ratio, torch.Tensor):
+                return None
+            else:
+                ratio = dyn.ratio
+        step = sinfo.native(device)
+        x2d, restore = engine.canonical_groups(tensor, view)
+        first = info.steps[0]
+        clamp = info.needs_dequant_saturation
+        deq_lo, deq_hi = first.quant_dtype.min_value, first.quant_dtype.max_value
+        both = want_dequant and want_quant
+        dq, codes, s, z = engine.fake_quant_fused_outer(
+            step, x2d, outer, outer_range.min, outer_range.max, deq_clamp=clamp, deq_lo=deq_lo, deq_hi=deq_hi,
+            range_max=rmax, range_min=rmin, ratio=ratio, out_dtype=dtype, want_dequant=want_dequant,
+            want_codes=want_quant)
+        quantized = zero = None
+        if want_quant:
+            quant_scale.append(QuantScale().append(s.view(keep)))
+            zero = z.view(keep) if sinfo.has_zero_point else torch.tensor(0, dtype=torch.float32, device=device)
+            if both:  # the reference's qdata aliases its in-place float32 dequantization buffer
+                codes = engine.dequantize_groups(step, codes, s, z if sinfo.has_zero_point else None, outer=outer,
+                                                 deq_clamp=clamp, deq_lo=deq_lo, deq_hi=deq_hi, out_dtype=torch.float32)
+            quantized = restore(codes)
+        return QuantTensor(dequantized=restore(dq) if want_dequant else None, quantized=quantized,
+                           scale=quant_scale if want_quant else None, zero=zero,
+                           view_shape=view if want_quant else None)
 
     def update(self, tensor_shape: torch.Size, default_dtype: torch.dtype | None, quant_range: QuantRange | None,
                range_bound: RangeBound | None) -> QuantInfo | None:

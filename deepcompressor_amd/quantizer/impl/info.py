@@ -92,6 +92,15 @@ class QuantScaleInfo:
     def is_single_level(self) -> bool:
         return len(self.scale_quant_dtypes) == 1 and not self.exponent_scale_quant_dtypes
 
+    def is_two_level_per_tensor(self) -> bool:
+        """Two linear scale levels and no power-of-two ones: one scale for the whole tensor (a float type), then one
+        per group relative to it -- the NVFP4 layout.  No zero point."""
+        if self.has_zero_point or self.exponent_scale_quant_dtypes or len(self.linear_scale_quant_dtypes) != 2:
+            return False
+        first, second = self.linear_scale_view_shapes
+        return (math.prod(first[0::2]) == 1 and math.prod(second[1::2]) == 1
+                and isinstance(self.linear_scale_quant_dtypes[0], torch.dtype))
+
     def native(self, device: torch.device) -> Step:
         """The dcq_step of this step on ``device`` (codebook tables live on the device)."""
         if device not in self._native:

@@ -106,6 +106,30 @@ int dcq_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, 
                           const float* range_max, const float* range_min, int32_t has_ratio, float ratio,
                           void* dequant, float* codes, float* scale, float* zero, dcq_stream_t stream);
 
+/* dcq_fake_quant_groups_outer: the LAST step of a progressive (two-step) quantizer in one pass, e.g. the uint4 g128
+ * step of QoQ on top of its per-channel sint8 step (quantizer/impl/base.py:211-279): the group's data is
+ * clamp(x / outer[g], outer_lo, outer_hi) (base.py:221-224, not rounded), measured, quantized with this step's scale
+ * and zero (any scale / zero dtype with one level, e.g. sint8 integer scales), dequantized, clamped to
+ * [deq_lo, deq_hi] when deq_clamp and multiplied back by outer[g] (base.py:270-278), written as `out_storage`.
+ * Other arguments as dcq_fake_quant_groups. */
+int dcq_fake_quant_groups_outer(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
+                                const float* outer, float outer_lo, float outer_hi, int32_t deq_clamp, float deq_lo,
+                                float deq_hi, const float* range_max, const float* range_min, int32_t has_ratio,
+                                float ratio, void* dequant, int32_t out_storage, float* codes, float* scale, float* zero,
+                                dcq_stream_t stream);
+
+/* dcq_fake_quant_groups_two_level: fake quantization with TWO scale levels, the first one per tensor -- NVFP4:
+ * float4 codes in groups of 16 with float8 group scales relative to one 16-bit scale of the whole tensor
+ * (quantize_scale, quantizer/impl/scale.py:20-64; examples/diffusion/configs/svdquant/nvfp4.yaml).  A reduction
+ * kernel finds max |x| of the tensor (into *tensor_absmax, caller-provided device float), then one pass computes
+ *     level0 = Q0(|max * ratio / q_span| / level0_span),   level1[g] = Q1(|group max * ratio / q_span| / level0),
+ *     scale[g] = level1[g] * level0 (zero -> 1),   codes, dequantized values
+ * with Q0 = `level0` (a float type), Q1 = step->scale (e.g. the float8 codebook).  No zero point.  Outputs are optional. */
+int dcq_fake_quant_groups_two_level(const dcq_step* step, const dcq_rounding* level0, float level0_span, const void* x,
+                                    int32_t storage, int64_t G, int64_t S, int32_t has_ratio, float ratio,
+                                    float* tensor_absmax, void* dequant, float* codes, float* level0_out,
+                                    float* level1_out, float* scale, dcq_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Building blocks of the general path (multi-level scales, progressive two-step configs, custom
  * quantization kernels).  Same references as above, one reference op chain per function.
