@@ -21,10 +21,25 @@ constexpr int kWave = 64;
 void set_error(const char* fmt, ...);
 int hip_check(hipError_t e, const char* what);
 
+// The previous step of a progressive quantizer as the last step sees it: the step quantizes
+// clamp(x / scale[g], lo, hi) and multiplies its (optionally clamped) de-quantized values by scale[g].
+struct OuterStep {
+  const float* scale;  // [G], device
+  float lo, hi;
+  int deq_clamp;
+  float deq_lo, deq_hi;
+};
+
 // lean fused kernel (dcq_fused.hip); DCQ_ERR_UNSUPPORTED means "use the general kernel"
 int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t G, int64_t S, const float* range_max,
                          const float* range_min, int has_ratio, float ratio, void* dequant, float* codes, float* scale,
-                         float* zero, hipStream_t stream);
+                         float* zero, hipStream_t stream, const OuterStep* outer = nullptr);
+
+// lean kernel for value-table (floating-point) dtypes without zero point, one or two scale levels (dcq_fused.hip)
+int try_launch_fused_table(const dcq_step& st, const void* x, int storage, int64_t G, int64_t S, int has_ratio,
+                           float ratio, const float* tensor_absmax, const dcq_rounding* level0, float level0_span,
+                           void* dequant, float* codes, float* level0_out, float* level1_out, float* scale,
+                           float* zero, hipStream_t stream);
 
 // float -> storage dtype -> double of a power's exponent: torch rounds the scalar exponent of Tensor.pow_ to the tensor's
 // dtype (dcq_search.hip)

@@ -29,10 +29,17 @@ struct FusedParams {
   int32_t has_ratio;
   float ratio;
   float q_lo, q_hi;     // tensor quant range
-  float z_lo, z_hi;     // zero range (PreScale)
+  float z_lo, z_hi;     // zero range (integer zero points)
+  float s_lo, s_hi;     // scale range (integer scales)
   float q_span, q_min;
   int32_t has_bound_min, has_bound_max;
   float bound_min, bound_max;
+  // last step of a progressive quantizer: the step sees clamp(x / outer[g], outer_lo, outer_hi) and its de-quantized
+  // values are (optionally clamped, then) multiplied by outer[g] again
+  const float* outer;
+  float outer_lo, outer_hi;
+  int32_t deq_clamp;
+  float deq_lo, deq_hi;
 };
 
 __device__ __forceinline__ uint16_t bf16_rne_hw(float x) {
@@ -117,8 +124,10 @@ __device__ __forceinline__ float team_reduce(float v, int TL) {
 
 __device__ __forceinline__ float clamp_f(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 
+// One rounding of a scale (or of a zero point kept in the scale's dtype); lo / hi only matter for an integer dtype.
 template <int SK>
-__device__ __forceinline__ float round_scale(float v) {
+__device__ __forceinline__ float round_scale(float v, float lo, float hi) {
+  if (SK == DCQ_ROUND_INT) return fminf(fmaxf(rintf(v), lo), hi);
   if (SK == DCQ_ROUND_F16) return f16_to_f32(f32_to_f16(v));
   if (SK == DCQ_ROUND_BF16) return __uint_as_float(static_cast<uint32_t>(bf16_rne_hw(v)) << 16);
   return v;
@@ -130,7 +139,29 @@ __device__ __forceinline__ float round_scale(float v) {
 #define DCQ_FUSED_U 1
 #endif
 
-template <int ST, int ZD, int SK, bool SINGLE>
+// x[i] / outer for the elements of one 16-byte piece, clamped to the previous step's range
+template <int VEC>
+__device__ __forceinline__ void develop(float* v, float outer, const Divisor& d, const FusedParams& p) {
+  float raw_abs = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) raw_abs = fmaxf(raw_abs, fabsf(v[i]));
+  if (d.fast && raw_abs <= 0x1p60f) {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 2) {
+      const f32x2 t = div_fast2(f32x2{v[i], v[i + 1]}, d);
+      v[i] = t.x;
+      v[i + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = v[i] / outer;
+  }
+  // med3 == fminf(fmaxf(v, lo), hi), NaN included (both give lo)
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) v[i] = clamp_f(v[i], p.outer_lo, p.outer_hi);
+}
+
+template <int ST, int ZD, int SK, bool SINGLE, bool OUTER>
 __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
   using E = Elem<ST>;
   using raw_t = typename E::raw_t;
@@ -146,8 +177,11 @@ __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
   constexpr int U = SINGLE ? DCQ_FUSED_U : 1;  // groups in flight per team: more bytes outstanding per lane
   for (int64_t g0 = team0; g0 < p.G; g0 += nteams * U) {
     raw_t keep[U];
+    float held[U][VEC];  // one-chunk groups: the lane's values as the step sees them, computed once
     float s[U], z[U];
     Divisor dv[U];
+    float outer[U];
+    Divisor d_outer[U];
     bool live[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -161,6 +195,10 @@ __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
       const raw_t* xg = xin + g * raws_per_group;
       float vmax, vmin = 0.0f;
       float local_abs = INFINITY;  // bound on |x| over the elements THIS lane will quantize
+      if (OUTER) {
+        outer[u] = p.outer[g];
+        d_outer[u] = make_divisor(outer[u], 0.0f);
+      }
       if (p.range_max == nullptr) {
         float mx = ZD == DCQ_ZERO_NONE ? 0.0f : -INFINITY, mn = INFINITY;
         for (int c = 0; c < (SINGLE ? 1 : p.chunks); ++c) {
@@ -169,6 +207,11 @@ __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
             E::unpack(live[u] ? keep[u] : keep[0], v);
           } else {
             E::unpack(xg[static_cast<int64_t>(c) * TL + tl], v);
+          }
+          if (OUTER) develop<VEC>(v, outer[u], d_outer[u], p);
+          if (SINGLE) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) held[u][i] = v[i];
           }
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
@@ -197,19 +240,23 @@ __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
         if (SINGLE) {
           float v[VEC];
           E::unpack(live[u] ? keep[u] : keep[0], v);
+          if (OUTER) develop<VEC>(v, outer[u], d_outer[u], p);
           local_abs = 0.0f;
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) local_abs = fmaxf(local_abs, fabsf(v[i]));
+          for (int i = 0; i < VEC; ++i) {
+            held[u][i] = v[i];
+            local_abs = fmaxf(local_abs, fabsf(v[i]));
+          }
         }
       }
       if (p.has_bound_max) vmax = fminf(vmax, p.bound_max);
       if (ZD != DCQ_ZERO_NONE && p.has_bound_min) vmin = fmaxf(vmin, p.bound_min);
       const float span = ZD != DCQ_ZERO_NONE ? vmax - vmin : vmax;
-      float sc = round_scale<SK>(fabsf(span / p.q_span));
+      float sc = round_scale<SK>(fabsf(span / p.q_span), p.s_lo, p.s_hi);
       if (sc == 0.0f) sc = 1.0f;
       float ze = 0.0f;
       if (ZD == DCQ_ZERO_PRE_SCALE) ze = fminf(fmaxf(rintf(p.q_min - vmin / sc), p.z_lo), p.z_hi);
-      if (ZD == DCQ_ZERO_POST_SCALE) ze = round_scale<SK>(p.q_min * sc - vmin);
+      if (ZD == DCQ_ZERO_POST_SCALE) ze = round_scale<SK>(p.q_min * sc - vmin, p.z_lo, p.z_hi);
       s[u] = sc;
       z[u] = ze;
       dv[u] = make_divisor(sc, local_abs + fabsf(ze));
@@ -225,9 +272,14 @@ __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
       const raw_t* xg = xin + g * raws_per_group;
       for (int c = 0; c < (SINGLE ? 1 : p.chunks); ++c) {
         const int64_t off = static_cast<int64_t>(c) * TL + tl;
-        const raw_t raw = SINGLE ? keep[u] : xg[off];
         float v[VEC], d[VEC], qv[VEC];
-        E::unpack(raw, v);
+        if (SINGLE) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[i] = held[u][i];
+        } else {
+          E::unpack(xg[off], v);
+          if (OUTER) develop<VEC>(v, outer[u], d_outer[u], p);
+        }
         if (dv[u].fast) {
 #pragma unroll
           for (int i = 0; i < VEC; i += 2) {
@@ -258,6 +310,14 @@ __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
             d[i] = from_code<ZD>(qv[i], s[u], z[u]);
           }
         }
+        if (OUTER) {
+          if (p.deq_clamp) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) d[i] = clamp_f(d[i], p.deq_lo, p.deq_hi);
+          }
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) d[i] = d[i] * outer[u];
+        }
         if (dq_out) dq_out[g * raws_per_group + off] = E::pack(d);
         if (p.codes) {
           float4* co = reinterpret_cast<float4*>(p.codes + (g * raws_per_group + off) * VEC);
@@ -280,12 +340,17 @@ static int launch_fused(const FusedParams& p, hipStream_t stream) {
   // ~8 % slower, an un-looped grid 3-8 %; non-temporal loads / stores change nothing
   constexpr int64_t kGridCap = 8192;
   if (blocks > kGridCap) blocks = kGridCap;
-  if (p.chunks == 1) {
-    hipLaunchKernelGGL((fused_int_kernel<ST, ZD, SK, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,
-                       p);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  if (p.outer) {
+    if (p.chunks == 1) {
+      hipLaunchKernelGGL((fused_int_kernel<ST, ZD, SK, true, true>), grid, block, 0, stream, p);
+    } else {
+      hipLaunchKernelGGL((fused_int_kernel<ST, ZD, SK, false, true>), grid, block, 0, stream, p);
+    }
+  } else if (p.chunks == 1) {
+    hipLaunchKernelGGL((fused_int_kernel<ST, ZD, SK, true, false>), grid, block, 0, stream, p);
   } else {
-    hipLaunchKernelGGL((fused_int_kernel<ST, ZD, SK, false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,
-                       p);
+    hipLaunchKernelGGL((fused_int_kernel<ST, ZD, SK, false, false>), grid, block, 0, stream, p);
   }
   DCQ_LAUNCH_CHECK("fused_int_kernel launch");
   return DCQ_OK;
@@ -298,6 +363,8 @@ static int fused_scale_kind(const FusedParams& p, int sk, hipStream_t stream) {
       return launch_fused<ST, ZD, DCQ_ROUND_F16>(p, stream);
     case DCQ_ROUND_BF16:
       return launch_fused<ST, ZD, DCQ_ROUND_BF16>(p, stream);
+    case DCQ_ROUND_INT:
+      return launch_fused<ST, ZD, DCQ_ROUND_INT>(p, stream);
     default:
       return launch_fused<ST, ZD, DCQ_ROUND_F32>(p, stream);
   }
@@ -319,9 +386,10 @@ static int fused_zero(const FusedParams& p, int zd, int sk, hipStream_t stream) 
 // lean kernel; the caller then uses the general kernel.
 int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t G, int64_t S, const float* range_max,
                          const float* range_min, int has_ratio, float ratio, void* dequant, float* codes, float* scale,
-                         float* zero, hipStream_t stream) {
+                         float* zero, hipStream_t stream, const OuterStep* outer) {
   const int sk = st.scale.kind;
-  const bool scale_ok = (sk == DCQ_ROUND_F32 || sk == DCQ_ROUND_F16 || sk == DCQ_ROUND_BF16) && !st.scale.has_clamp;
+  const bool scale_ok =
+      (sk == DCQ_ROUND_F32 || sk == DCQ_ROUND_F16 || sk == DCQ_ROUND_BF16 || sk == DCQ_ROUND_INT) && !st.scale.has_clamp;
   bool zero_ok = true;
   if (st.zero_domain == DCQ_ZERO_PRE_SCALE) zero_ok = st.zero.kind == DCQ_ROUND_INT;
   if (st.zero_domain == DCQ_ZERO_POST_SCALE) zero_ok = st.zero.kind == sk && !st.zero.has_clamp;
@@ -352,12 +420,22 @@ int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t
   p.q_hi = st.tensor.hi;
   p.z_lo = st.zero.lo;
   p.z_hi = st.zero.hi;
+  p.s_lo = st.scale.lo;
+  p.s_hi = st.scale.hi;
   p.q_span = st.q_span;
   p.q_min = st.q_min;
   p.has_bound_min = st.has_bound_min;
   p.has_bound_max = st.has_bound_max;
   p.bound_min = st.bound_min;
   p.bound_max = st.bound_max;
+  if (outer != nullptr && outer->scale != nullptr) {
+    p.outer = outer->scale;
+    p.outer_lo = outer->lo;
+    p.outer_hi = outer->hi;
+    p.deq_clamp = outer->deq_clamp;
+    p.deq_lo = outer->deq_lo;
+    p.deq_hi = outer->deq_hi;
+  }
   switch (storage) {
     case DCQ_F32:
       return fused_zero<DCQ_F32>(p, st.zero_domain, sk, stream);
@@ -365,6 +443,340 @@ int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t
       return fused_zero<DCQ_F16>(p, st.zero_domain, sk, stream);
     default:
       return fused_zero<DCQ_BF16>(p, st.zero_domain, sk, stream);
+  }
+}
+
+// =============================================================================================
+// Floating-point quantization dtypes (value tables such as fp4 e2m1) without a zero point, the scale in one level or
+// in two with the first level per tensor (NVFP4: the largest group scale of the tensor, float; every group's scale
+// relative to it, fp8).  Same single read and single write as the kernel above.  Two things keep it off the VALU:
+//
+//   * rounding to the table is one LDS lookup, not a search: when every table value is a multiple of a power of two
+//     `cell` (true of minifloat tables: 0.5 for e2m1), the two neighbours of any x in [k cell, (k+1) cell) are the
+//     same pair, so a list of (below, above) per cell, built in LDS by each workgroup from the table, leaves one
+//     comparison x + x < below + above per element -- the reference's own tie rule (ties go up).  A table that is not
+//     on such a grid (or needs more than kMaxCells cells) is searched as in the general kernel;
+//   * groups of two 16-byte pieces (16 values of a 16-bit tensor) are owned by ONE lane, so the scale -- two divisions
+//     and a search of the fp8 table -- is computed once per group instead of once per piece.  Loads and stores stay
+//     fully coalesced: a wave moves 128 consecutive pieces with two instructions and neighbouring lanes swap one piece
+//     each (a DPP move) so that even lanes hold groups 0..31 and odd lanes groups 32..63 of the wave's 64.
+// =============================================================================================
+constexpr int kMaxCells = 1024;
+
+struct CodebookParams {
+  dcq_step step;
+  const void* x;
+  void* dequant;
+  float* codes;
+  float* scale_out;
+  float* zero_out;  // receives 0 for every group (there is no zero point)
+  int64_t G;
+  int32_t S;
+  int32_t team_lanes;
+  int32_t team_shift;
+  int32_t has_ratio;
+  float ratio;
+  // two scale levels: device scalar holding the tensor's largest magnitude, the first level's rounding and span
+  const float* tensor_absmax;
+  dcq_rounding level0;
+  float level0_span;
+  float* level0_out;
+  float* level1_out;
+};
+
+struct CodebookLut {
+  float tensor[256];
+  float scale[256];
+  float4 pair[kMaxCells + 1];
+  unsigned gap_bits;
+  int on_grid;
+};
+
+// Stages the tables and builds the per-cell neighbour list; returns the cell size (0: no grid, search instead).
+__device__ __forceinline__ float build_lut(const CodebookParams& p, CodebookLut& lds, float& first_cell,
+                                           unsigned& cells) {
+  const int C = p.step.tensor.codebook_size;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) lds.tensor[i] = p.step.tensor.codebook[i];
+  if (p.step.scale.kind == DCQ_ROUND_CODEBOOK)
+    for (int i = threadIdx.x; i < p.step.scale.codebook_size; i += blockDim.x) lds.scale[i] = p.step.scale.codebook[i];
+  if (threadIdx.x == 0) {
+    lds.gap_bits = 0x7f7fffffu;
+    lds.on_grid = 1;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i + 1 < C; i += blockDim.x) {
+    const float gap = lds.tensor[i + 1] - lds.tensor[i];
+    if (gap > 0.0f) atomicMin(&lds.gap_bits, __float_as_uint(gap));  // positive floats order like their bit patterns
+  }
+  __syncthreads();
+  // the power of two at or below the smallest gap, then up to three halvings (tables with 1.5-spaced values)
+  float cell = __uint_as_float(lds.gap_bits & 0x7f800000u);
+  float found = 0.0f;
+  for (int attempt = 0; attempt < 4; ++attempt, cell *= 0.5f) {
+    const float inv = 1.0f / cell;  // exact
+    bool ok = cell >= 0x1p-100f && cell <= 0x1p100f;
+    if (ok) {
+      for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        const float k = lds.tensor[i] * inv;
+        if (!(fabsf(k) < 0x1p22f) || k != rintf(k)) ok = false;
+      }
+      const float span = (lds.tensor[C - 1] - lds.tensor[0]) * inv;
+      if (!(span <= static_cast<float>(kMaxCells))) ok = false;
+    }
+    if (!ok) lds.on_grid = 0;
+    __syncthreads();
+    const bool all_ok = lds.on_grid != 0;
+    __syncthreads();
+    if (all_ok) {
+      found = cell;
+      break;
+    }
+    if (threadIdx.x == 0) lds.on_grid = 1;
+    __syncthreads();
+  }
+  if (found == 0.0f) return 0.0f;
+  const float inv = 1.0f / found;
+  first_cell = lds.tensor[0] * inv;
+  cells = static_cast<unsigned>(lds.tensor[C - 1] * inv - first_cell);
+  for (unsigned c = threadIdx.x; c <= cells; c += blockDim.x) {
+    const float start = (static_cast<float>(c) + first_cell) * found;  // exact
+    int lo = 0;
+    for (int bit = 1 << (31 - __clz(C)); bit; bit >>= 1) {
+      const int next = lo | bit;
+      if (next < C && lds.tensor[next] <= start) lo = next;
+    }
+    // x + x < below + above, the reference's comparison, is x < (below + above) / 2: halving the rounded sum is exact
+    const float below = lds.tensor[lo], above = lds.tensor[lo + (lo < C - 1)];
+    lds.pair[c] = make_float4(below, above, (below + above) * 0.5f, 0.0f);
+  }
+  __syncthreads();
+  return found;
+}
+
+struct GridRound {
+  float inv_cell;  // 0: search the table
+  float first_cell;
+  unsigned cells;
+};
+
+__device__ __forceinline__ float round_to_table(float t, const dcq_rounding& r, const GridRound& gr,
+                                                const CodebookLut& lds) {
+  float y;
+  const float c = clamp_f(t, r.lo, r.hi);  // == fminf(fmaxf(t, lo), hi), NaN included (both give lo)
+  if (gr.inv_cell != 0.0f) {
+    // cell number relative to the table's first value; the float -> unsigned conversion truncates (a floor: the
+    // operand is >= 0, anything below converts to 0).  The one rounding of the fused multiply-add can only move an x
+    // within half an ulp of a cell's upper edge into the next cell, whose pair decides such an x the same way.
+    const unsigned cell = min(static_cast<unsigned>(__builtin_fmaf(c, gr.inv_cell, -gr.first_cell)), gr.cells);
+    const float4 nb = lds.pair[cell];  // below, above, (below + above) / 2
+    y = c < nb.z ? nb.x : nb.y;
+  } else {
+    y = codebook_nearest(c, lds.tensor, r.codebook_size);
+  }
+  if (r.has_clamp) y = clamp_f(y, r.clamp_lo, r.clamp_hi);
+  return y;
+}
+
+// Scale of one group from its largest magnitude (quantizer/impl/scale.py:46-62 for two levels).
+__device__ __forceinline__ float table_group_scale(const CodebookParams& p, const CodebookLut& lds, float vmax,
+                                                   float level0, float& level1) {
+  const dcq_step& st = p.step;
+  if (p.has_ratio) vmax = vmax * p.ratio;
+  if (st.has_bound_max) vmax = fminf(vmax, st.bound_max);
+  float s;
+  if (p.tensor_absmax) {
+    level1 = apply_rounding(st.scale, fabsf(vmax / st.q_span) / level0, lds.scale);
+    s = level1 * level0;
+  } else {
+    s = apply_rounding(st.scale, fabsf(vmax / st.q_span), lds.scale);
+    level1 = s;
+  }
+  return s == 0.0f ? 1.0f : s;
+}
+
+// N pieces of one group held by one lane: quantize in place (v -> de-quantized), codes to q
+template <int N>
+__device__ __forceinline__ void quantize_to_table(float* v, float* q, float s, float local_abs, const dcq_rounding& r,
+                                                  const GridRound& gr, const CodebookLut& lds) {
+  const Divisor d = make_divisor(s, local_abs);
+  if (d.fast) {
+#pragma unroll
+    for (int i = 0; i < N; i += 2) {
+      const f32x2 t = div_fast2(f32x2{v[i], v[i + 1]}, d);
+      q[i] = round_to_table(t.x, r, gr, lds);
+      q[i + 1] = round_to_table(t.y, r, gr, lds);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = round_to_table(v[i] / s, r, gr, lds);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = q[i] * s;
+}
+
+template <typename RAW>
+__device__ __forceinline__ RAW swap_with_neighbour(const RAW& r) {
+  RAW out;
+  const uint32_t* in = reinterpret_cast<const uint32_t*>(&r);
+  uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    o[i] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(in[i]), 0xB1, 0xf, 0xf, false));
+  return out;
+}
+
+template <int ST, bool PAIRED>
+__global__ __launch_bounds__(256) void fused_table_kernel(const CodebookParams p) {
+  using E = Elem<ST>;
+  using raw_t = typename E::raw_t;
+  constexpr int VEC = E::kVec;
+  __shared__ CodebookLut lds;
+  GridRound gr;
+  gr.first_cell = 0.0f;
+  gr.cells = 0;
+  const float cell = build_lut(p, lds, gr.first_cell, gr.cells);
+  gr.inv_cell = cell != 0.0f ? 1.0f / cell : 0.0f;
+  const dcq_step& st = p.step;
+  const raw_t* xin = static_cast<const raw_t*>(p.x);
+  raw_t* dq_out = static_cast<raw_t*>(p.dequant);
+
+  float level0 = 1.0f;
+  if (p.tensor_absmax) {
+    float top = *p.tensor_absmax;
+    if (p.has_ratio) top = top * p.ratio;
+    if (st.has_bound_max) top = fminf(top, st.bound_max);
+    level0 = apply_rounding(p.level0, fabsf(top / st.q_span) / p.level0_span, nullptr);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.level0_out) *p.level0_out = level0;
+  }
+
+  if (PAIRED) {
+    const int lane = threadIdx.x & 63;
+    const bool odd = lane & 1;
+    const int64_t wave = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * 4;
+    const int64_t pieces = p.G * 2;
+    for (int64_t w = wave; w * 64 < p.G; w += nwaves) {
+      const int64_t r0 = w * 128 + lane, r1 = r0 + 64;
+      raw_t a{}, b{};
+      if (r0 < pieces) a = xin[r0];
+      if (r1 < pieces) b = xin[r1];
+      // even lanes give away their second piece, odd lanes their first
+      const raw_t got = swap_with_neighbour(odd ? a : b);
+      const raw_t first = odd ? got : a, second = odd ? b : got;
+      const int64_t g = w * 64 + (odd ? 32 : 0) + (lane >> 1);
+      float v[2 * VEC], q[2 * VEC];
+      E::unpack(first, v);
+      E::unpack(second, v + VEC);
+      float mx = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 2 * VEC; ++i) mx = fmaxf(mx, fabsf(v[i]));
+      float level1;
+      const float s = table_group_scale(p, lds, mx, level0, level1);
+      quantize_to_table<2 * VEC>(v, q, s, mx, st.tensor, gr, lds);
+      if (g < p.G) {
+        if (p.scale_out) p.scale_out[g] = s;
+        if (p.zero_out) p.zero_out[g] = 0.0f;
+        if (p.level1_out) p.level1_out[g] = level1;
+        if (p.codes) {
+          float4* co = reinterpret_cast<float4*>(p.codes + g * (2 * VEC));
+#pragma unroll
+          for (int i = 0; i < 2 * VEC / 4; ++i) co[i] = make_float4(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
+        }
+      }
+      if (dq_out) {
+        const raw_t f = E::pack(v), sd = E::pack(v + VEC);
+        const raw_t back = swap_with_neighbour(odd ? f : sd);
+        const raw_t oa = odd ? back : f, ob = odd ? sd : back;
+        if (r0 < pieces) dq_out[r0] = oa;
+        if (r1 < pieces) dq_out[r1] = ob;
+      }
+    }
+  } else {
+    const int TL = p.team_lanes;
+    const int tl = threadIdx.x & (TL - 1);
+    const int64_t team0 = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> p.team_shift;
+    const int64_t nteams = (static_cast<int64_t>(gridDim.x) * 256) >> p.team_shift;
+    for (int64_t g = team0; g < p.G; g += nteams) {
+      const int64_t at = g * TL + tl;
+      float v[VEC], q[VEC];
+      E::unpack(xin[at], v);
+      float mx = 0.0f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) mx = fmaxf(mx, fabsf(v[i]));
+      const float vmax = team_reduce<true>(mx, TL);
+      float level1;
+      const float s = table_group_scale(p, lds, vmax, level0, level1);
+      quantize_to_table<VEC>(v, q, s, mx, st.tensor, gr, lds);
+      if (tl == 0) {
+        if (p.scale_out) p.scale_out[g] = s;
+        if (p.zero_out) p.zero_out[g] = 0.0f;
+        if (p.level1_out) p.level1_out[g] = level1;
+      }
+      if (p.codes) {
+        float4* co = reinterpret_cast<float4*>(p.codes + at * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC / 4; ++i) co[i] = make_float4(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
+      }
+      if (dq_out) dq_out[at] = E::pack(v);
+    }
+  }
+}
+
+template <int ST>
+static int launch_table(const CodebookParams& p, bool paired, hipStream_t stream) {
+  constexpr int64_t kGridCap = 8192;
+  if (paired) {
+    int64_t blocks = (p.G + 255) / 256;  // 64 groups per wave and pass
+    if (blocks > kGridCap) blocks = kGridCap;
+    hipLaunchKernelGGL((fused_table_kernel<ST, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
+  } else {
+    int64_t blocks = (p.G * p.team_lanes + 255) / 256;
+    if (blocks > kGridCap) blocks = kGridCap;
+    hipLaunchKernelGGL((fused_table_kernel<ST, false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
+  }
+  DCQ_LAUNCH_CHECK("fused_table_kernel launch");
+  return DCQ_OK;
+}
+
+// DCQ_ERR_UNSUPPORTED (no error text) when the configuration or the buffers need the general kernel.
+int try_launch_fused_table(const dcq_step& st, const void* x, int storage, int64_t G, int64_t S, int has_ratio,
+                           float ratio, const float* tensor_absmax, const dcq_rounding* level0, float level0_span,
+                           void* dequant, float* codes, float* level0_out, float* level1_out, float* scale,
+                           float* zero, hipStream_t stream) {
+  if (st.tensor.kind != DCQ_ROUND_CODEBOOK || st.zero_domain != DCQ_ZERO_NONE) return DCQ_ERR_UNSUPPORTED;
+  const int vec = storage == DCQ_F32 ? 4 : 8;
+  auto aligned = [](const void* ptr, uintptr_t a) { return ptr == nullptr || (reinterpret_cast<uintptr_t>(ptr) % a) == 0; };
+  if (S % vec != 0 || !aligned(x, 16) || !aligned(dequant, 16) || !aligned(codes, 16)) return DCQ_ERR_UNSUPPORTED;
+  const int64_t n = S / vec;
+  const bool paired = n == 2;
+  if (!paired && (n > 64 || (n & (n - 1)) != 0)) return DCQ_ERR_UNSUPPORTED;
+  CodebookParams p{};
+  p.step = st;
+  p.x = x;
+  p.dequant = dequant;
+  p.codes = codes;
+  p.scale_out = scale;
+  p.zero_out = zero;
+  p.G = G;
+  p.S = static_cast<int32_t>(S);
+  p.team_lanes = static_cast<int32_t>(n);
+  p.team_shift = __builtin_ctz(static_cast<unsigned>(n));
+  p.has_ratio = has_ratio;
+  p.ratio = ratio;
+  p.tensor_absmax = tensor_absmax;
+  if (tensor_absmax) {
+    p.level0 = *level0;
+    p.level0_span = level0_span;
+  }
+  p.level0_out = level0_out;
+  p.level1_out = level1_out;
+  switch (storage) {
+    case DCQ_F32:
+      return launch_table<DCQ_F32>(p, paired, stream);
+    case DCQ_F16:
+      return launch_table<DCQ_F16>(p, paired, stream);
+    default:
+      return launch_table<DCQ_BF16>(p, paired, stream);
   }
 }
 
@@ -466,11 +878,11 @@ __global__ __launch_bounds__(256) void smooth_int_kernel(const SmoothParams sp) 
       if (p.has_bound_max) vmax = fminf(vmax, p.bound_max);
       if (ZD != DCQ_ZERO_NONE && p.has_bound_min) vmin = fmaxf(vmin, p.bound_min);
       const float span = ZD != DCQ_ZERO_NONE ? vmax - vmin : vmax;
-      float sc = round_scale<SK>(fabsf(span / p.q_span));
+      float sc = round_scale<SK>(fabsf(span / p.q_span), 0.0f, 0.0f);
       if (sc == 0.0f) sc = 1.0f;
       float ze = 0.0f;
       if (ZD == DCQ_ZERO_PRE_SCALE) ze = fminf(fmaxf(rintf(p.q_min - vmin / sc), p.z_lo), p.z_hi);
-      if (ZD == DCQ_ZERO_POST_SCALE) ze = round_scale<SK>(p.q_min * sc - vmin);
+      if (ZD == DCQ_ZERO_POST_SCALE) ze = round_scale<SK>(p.q_min * sc - vmin, 0.0f, 0.0f);
       const Divisor dv = make_divisor(sc, local_abs + fabsf(ze));
       // ---- pass 2: quantize, dequantize, take the smoothing back, cast
       float acc = 0.0f;

@@ -113,6 +113,12 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
   for (int64_t g = team0; g < p.G; g += nteams) {
     const in_t* xg = xin + g * p.S;
     const float outer = p.outer ? p.outer[g] : 1.0f;
+    // x / outer for many x: the hoisted-reciprocal form of the IEEE division (bit-identical inside its guard, which
+    // is checked per element on |x|; see make_divisor)
+    const Divisor d_outer = make_divisor(outer, 0.0f);
+    auto by_outer = [&](float v) {
+      return (d_outer.fast && fabsf(v) <= 0x1p60f) ? div_fast(v, d_outer) : v / outer;
+    };
     Chunk<in_t, VEC> keep;  // the group's data when it fits one pass
     float s = 1.0f, z = 0.0f;
 
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
             float v = In::load(ch.v[i]);
-            if (p.outer) v = fminf(fmaxf(v / outer, p.outer_lo), p.outer_hi);
+            if (p.outer) v = fminf(fmaxf(by_outer(v), p.outer_lo), p.outer_hi);
             if (ZD == DCQ_ZERO_NONE) {
               mx = fmaxf(mx, fabsf(v));
             } else {
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
     }
 
     // second pass: codes and dequantized values
+    const Divisor d_scale = make_divisor(s, 0.0f);
     for (int c = 0; c < p.chunks; ++c) {
       const int64_t off = (static_cast<int64_t>(c) * TL + tl) * VEC;
       Chunk<in_t, VEC> ch;
@@ -208,8 +215,11 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
         float q;
         if (want_q) {
           float v = In::load(ch.v[i]);
-          if (p.outer) v = fminf(fmaxf(v / outer, p.outer_lo), p.outer_hi);
-          const float t = to_code_input<ZD>(v, s, z);
+          if (p.outer) v = fminf(fmaxf(by_outer(v), p.outer_lo), p.outer_hi);
+          float t = v;
+          if (ZD == DCQ_ZERO_POST_SCALE) t = t + z;
+          t = (d_scale.fast && fabsf(t) <= 0x1p60f) ? div_fast(t, d_scale) : t / s;
+          if (ZD == DCQ_ZERO_PRE_SCALE) t = t + z;
           if (p.round_delta) {  // integer types only (checked on the host): simple.py:47-51
             q = fminf(fmaxf(floorf(t) + delta.v[i], st.tensor.lo), st.tensor.hi);
           } else {
@@ -584,6 +594,11 @@ int dcq_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, 
   rc = try_launch_fused_int(*step, x, storage, G, S, range_max, range_min, has_ratio, ratio, dequant, codes, scale,
                             zero, static_cast<hipStream_t>(stream));
   if (rc != DCQ_ERR_UNSUPPORTED) return rc;
+  if (range_max == nullptr) {
+    rc = try_launch_fused_table(*step, x, storage, G, S, has_ratio, ratio, nullptr, nullptr, 0.0f, dequant, codes,
+                                nullptr, nullptr, scale, zero, static_cast<hipStream_t>(stream));
+    if (rc != DCQ_ERR_UNSUPPORTED) return rc;
+  }
   GroupParams p{};
   p.step = *step;
   p.x = x;
@@ -616,6 +631,12 @@ int dcq_fake_quant_groups_outer(const dcq_step* step, const void* x, int32_t sto
   DCQ_REQUIRE(!(range_max && step->zero_domain != DCQ_ZERO_NONE && !range_min), DCQ_ERR_ARGUMENT,
               "a static range with a zero point needs range_min");
   DCQ_REQUIRE(!(range_max && has_ratio), DCQ_ERR_UNSUPPORTED, "ratio together with a static range");
+  if (dequant == nullptr || out_storage == storage) {
+    const OuterStep prev{outer, outer_lo, outer_hi, deq_clamp, deq_lo, deq_hi};
+    rc = try_launch_fused_int(*step, x, storage, G, S, range_max, range_min, has_ratio, ratio, dequant, codes, scale,
+                              zero, static_cast<hipStream_t>(stream), &prev);
+    if (rc != DCQ_ERR_UNSUPPORTED) return rc;
+  }
   GroupParams p{};
   p.step = *step;
   p.x = x;
@@ -674,6 +695,9 @@ int dcq_fake_quant_groups_two_level(const dcq_step* step, const dcq_rounding* le
       return DCQ_ERR_ARGUMENT;
   }
   DCQ_LAUNCH_CHECK("tensor_absmax_kernel launch");
+  rc = try_launch_fused_table(*step, x, storage, G, S, has_ratio, ratio, tensor_absmax, level0, level0_span, dequant,
+                              codes, level0_out, level1_out, scale, nullptr, s);
+  if (rc != DCQ_ERR_UNSUPPORTED) return rc;
   GroupParams p{};
   p.step = *step;
   p.x = x;
