@@ -81,6 +81,8 @@ _SIGNATURES = {
     "dcq_gemm_f64": [_p, _i32, _i64, _i32, _i64, _p, _i32, _i64, _i64, _p, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "dcq_fake_quant_groups_outer": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _f, _f, _i32, _f, _f, _p, _p, _i32, _f, _p,
                                     _i32, _p, _p, _p, _p],
+    "dcq_fake_quant_progressive": [C.POINTER(Step), C.POINTER(Step), _p, _i32, _i64, _i64, _i64, _i32, _f, _i32, _f, _f, _f,
+                                   _i32, _f, _f, _p, _p, _p, _p, _p, _p],
     "dcq_fake_quant_groups_two_level": [C.POINTER(Step), C.POINTER(Rounding), _f, _p, _i32, _i64, _i64, _i32, _f, _p, _p,
                                         _p, _p, _p, _p, _p],
     "dcq_smooth_fake_quant_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _i64, _p, _i32, _i32, _i32, _f, _p, _p, _d,

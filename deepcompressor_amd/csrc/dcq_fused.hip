@@ -110,13 +110,33 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
+// One butterfly step as a single VALU instruction: max / min of a lane's value with the DPP-permuted one.  (Written
+// as asm because the compiler emits a v_mov_dpp plus two canonicalising v_max per step; the leading s_nop covers the
+// two wait states a DPP read needs after the VALU write of its source, which the compiler cannot see inside asm.)
+#define DCQ_DPP_STEP(NAME, CTRL)                                                                   \
+  template <bool IS_MAX>                                                                           \
+  __device__ __forceinline__ float NAME(float v) {                                                 \
+    float r;                                                                                       \
+    if (IS_MAX) {                                                                                  \
+      asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v)); \
+    } else {                                                                                       \
+      asm("s_nop 1\n\tv_min_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v)); \
+    }                                                                                              \
+    return r;                                                                                      \
+  }
+DCQ_DPP_STEP(step_pairs, "quad_perm:[1,0,3,2]")
+DCQ_DPP_STEP(step_quads, "quad_perm:[2,3,0,1]")
+DCQ_DPP_STEP(step_half_rows, "row_half_mirror")
+DCQ_DPP_STEP(step_rows, "row_mirror")
+#undef DCQ_DPP_STEP
+
 template <bool IS_MAX>
 __device__ __forceinline__ float team_reduce(float v, int TL) {
   auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : fminf(a, b); };
-  if (TL >= 2) v = op(v, dpp_move<0xB1>(v));   // quad_perm [1,0,3,2]
-  if (TL >= 4) v = op(v, dpp_move<0x4E>(v));   // quad_perm [2,3,0,1]
-  if (TL >= 8) v = op(v, dpp_move<0x141>(v));  // row_half_mirror
-  if (TL >= 16) v = op(v, dpp_move<0x140>(v));  // row_mirror
+  if (TL >= 2) v = step_pairs<IS_MAX>(v);
+  if (TL >= 4) v = step_quads<IS_MAX>(v);
+  if (TL >= 8) v = step_half_rows<IS_MAX>(v);
+  if (TL >= 16) v = step_rows<IS_MAX>(v);
   if (TL >= 32) v = op(v, __shfl_xor(v, 16, kWave));
   if (TL >= 64) v = op(v, __shfl_xor(v, 32, kWave));
   return v;
@@ -445,6 +465,284 @@ int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t
       return fused_zero<DCQ_BF16>(p, st.zero_domain, sk, stream);
   }
 }
+
+// =============================================================================================
+// Two progressive steps in one pass (QoQ-style W4: a float scale per row from the row's largest magnitude, then an
+// integer step on groups of clamp(x / row scale) inside the row): one workgroup holds a row in registers, reduces
+// its largest magnitude through LDS, and every team of lanes then runs the last step on its group exactly as
+// fused_int_kernel<OUTER> does -- the row scale never leaves the chip and the tensor is read once.
+// =============================================================================================
+constexpr int kMaxRowPieces = 8;  // 16-byte pieces per thread: rows of up to 256 * 8 * (4 | 8) values
+
+struct ProgressiveParams {
+  FusedParams last;        // last.outer unused (the row scale is computed here); last.outer_lo / hi / deq_* used
+  dcq_rounding first_scale;
+  float first_q_span;
+  int32_t first_has_ratio;
+  float first_ratio;
+  int32_t first_has_bound_max;
+  float first_bound_max;
+  float* first_scale_out;  // [rows]
+  int64_t rows;
+  int32_t row_pieces;      // 16-byte pieces per row
+  int32_t groups_per_row;
+};
+
+template <int ST, int ZD, int SK, int PIECES>
+__global__ __launch_bounds__(256) void progressive_int_kernel(const ProgressiveParams pp) {
+  using E = Elem<ST>;
+  using raw_t = typename E::raw_t;
+  constexpr int VEC = E::kVec;
+  const FusedParams& p = pp.last;
+  __shared__ float part[2][4];
+  const int TL = p.team_lanes;
+  const int tid = threadIdx.x;
+  const raw_t* xin = static_cast<const raw_t*>(p.x);
+  raw_t* dq_out = static_cast<raw_t*>(p.dequant);
+  int parity = 0;
+  for (int64_t row = blockIdx.x; row < pp.rows; row += gridDim.x, parity ^= 1) {
+    const int64_t base = row * pp.row_pieces;
+    raw_t keep[PIECES];
+    float mx = 0.0f;
+#pragma unroll
+    for (int c = 0; c < PIECES; ++c) {
+      const int j = c * 256 + tid;
+      if (j < pp.row_pieces) {
+        keep[c] = xin[base + j];
+        float v[VEC];
+        E::unpack(keep[c], v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) mx = fmaxf(mx, fabsf(v[i]));
+      }
+    }
+    mx = team_reduce<true>(mx, 64);
+    if ((tid & 63) == 0) part[parity][tid >> 6] = mx;
+    __syncthreads();  // one barrier per row: the next row writes the other half of `part`
+    float top = fmaxf(fmaxf(part[parity][0], part[parity][1]), fmaxf(part[parity][2], part[parity][3]));
+    if (pp.first_has_ratio) top = top * pp.first_ratio;
+    if (pp.first_has_bound_max) top = fminf(top, pp.first_bound_max);
+    float outer = apply_rounding(pp.first_scale, fabsf(top / pp.first_q_span), nullptr);
+    if (outer == 0.0f) outer = 1.0f;
+    if (tid == 0) pp.first_scale_out[row] = outer;
+    const Divisor d_outer = make_divisor(outer, 0.0f);
+#pragma unroll
+    for (int c = 0; c < PIECES; ++c) {
+      const int j = c * 256 + tid;
+      if (j >= pp.row_pieces) continue;  // whole teams leave together: a group never straddles the row's end
+      float v[VEC], d[VEC], qv[VEC];
+      E::unpack(keep[c], v);
+      develop<VEC>(v, outer, d_outer, p);
+      float lmx = ZD == DCQ_ZERO_NONE ? 0.0f : -INFINITY, lmn = INFINITY;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        if (ZD == DCQ_ZERO_NONE) {
+          lmx = fmaxf(lmx, fabsf(v[i]));
+        } else {
+          lmx = fmaxf(lmx, v[i]);
+          lmn = fminf(lmn, v[i]);
+        }
+      }
+      const float local_abs = ZD == DCQ_ZERO_NONE ? lmx : fmaxf(fabsf(lmx), fabsf(lmn));
+      float vmax = team_reduce<true>(lmx, TL), vmin = 0.0f;
+      if (ZD != DCQ_ZERO_NONE) vmin = team_reduce<false>(lmn, TL);
+      if (p.has_ratio) {
+        vmax = vmax * p.ratio;
+        if (ZD != DCQ_ZERO_NONE) vmin = vmin * p.ratio;
+      }
+      if (ZD == DCQ_ZERO_PRE_SCALE) {
+        vmax = fmaxf(vmax, 0.0f);
+        vmin = fminf(vmin, 0.0f);
+      }
+      if (p.has_bound_max) vmax = fminf(vmax, p.bound_max);
+      if (ZD != DCQ_ZERO_NONE && p.has_bound_min) vmin = fmaxf(vmin, p.bound_min);
+      const float span = ZD != DCQ_ZERO_NONE ? vmax - vmin : vmax;
+      float sc = round_scale<SK>(fabsf(span / p.q_span), p.s_lo, p.s_hi);
+      if (sc == 0.0f) sc = 1.0f;
+      float ze = 0.0f;
+      if (ZD == DCQ_ZERO_PRE_SCALE) ze = fminf(fmaxf(rintf(p.q_min - vmin / sc), p.z_lo), p.z_hi);
+      if (ZD == DCQ_ZERO_POST_SCALE) ze = round_scale<SK>(p.q_min * sc - vmin, p.z_lo, p.z_hi);
+      const Divisor dv = make_divisor(sc, local_abs + fabsf(ze));
+      const int64_t g = row * pp.groups_per_row + (j >> p.team_shift);
+      if ((tid & (TL - 1)) == 0) {
+        if (p.scale_out) p.scale_out[g] = sc;
+        if (p.zero_out) p.zero_out[g] = ze;
+      }
+      if (dv.fast) {
+#pragma unroll
+        for (int i = 0; i < VEC; i += 2) {
+          f32x2 a = {v[i], v[i + 1]};
+          const f32x2 zz = {ze, ze}, ss = {sc, sc};
+          if (ZD == DCQ_ZERO_POST_SCALE) a = a + zz;
+          f32x2 t = div_fast2(a, dv);
+          if (ZD == DCQ_ZERO_PRE_SCALE) t = t + zz;
+          const f32x2 q = {clamp_f(rintf(t.x), p.q_lo, p.q_hi), clamp_f(rintf(t.y), p.q_lo, p.q_hi)};
+          qv[i] = q.x;
+          qv[i + 1] = q.y;
+          f32x2 o;
+          if (ZD == DCQ_ZERO_PRE_SCALE) {
+            o = (q - zz) * ss;
+          } else if (ZD == DCQ_ZERO_POST_SCALE) {
+            o = q * ss - zz;
+          } else {
+            o = q * ss;
+          }
+          d[i] = o.x;
+          d[i + 1] = o.y;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float t = to_code_input<ZD>(v[i], sc, ze);
+          qv[i] = fminf(fmaxf(rintf(t), p.q_lo), p.q_hi);
+          d[i] = from_code<ZD>(qv[i], sc, ze);
+        }
+      }
+      if (p.deq_clamp) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d[i] = clamp_f(d[i], p.deq_lo, p.deq_hi);
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) d[i] = d[i] * outer;
+      if (dq_out) dq_out[base + j] = E::pack(d);
+      if (p.codes) {
+        float4* co = reinterpret_cast<float4*>(p.codes + (base + j) * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC / 4; ++i) co[i] = make_float4(qv[4 * i], qv[4 * i + 1], qv[4 * i + 2], qv[4 * i + 3]);
+      }
+    }
+  }
+}
+
+// PIECES: 16-byte pieces a thread holds (the row in registers); fewer registers, more waves in flight
+template <int ST, int ZD, int SK>
+static int progressive_launch(const ProgressiveParams& pp, hipStream_t stream) {
+  const dim3 grid(static_cast<unsigned>(pp.rows < 8192 ? pp.rows : 8192)), block(256);
+  if (pp.row_pieces <= 256 * 2) {
+    hipLaunchKernelGGL((progressive_int_kernel<ST, ZD, SK, 2>), grid, block, 0, stream, pp);
+  } else if (pp.row_pieces <= 256 * 4) {
+    hipLaunchKernelGGL((progressive_int_kernel<ST, ZD, SK, 4>), grid, block, 0, stream, pp);
+  } else {
+    hipLaunchKernelGGL((progressive_int_kernel<ST, ZD, SK, kMaxRowPieces>), grid, block, 0, stream, pp);
+  }
+  DCQ_LAUNCH_CHECK("progressive_int_kernel launch");
+  return DCQ_OK;
+}
+
+template <int ST, int ZD>
+static int progressive_scale_kind(const ProgressiveParams& pp, int sk, hipStream_t stream) {
+  switch (sk) {
+    case DCQ_ROUND_F16:
+      return progressive_launch<ST, ZD, DCQ_ROUND_F16>(pp, stream);
+    case DCQ_ROUND_BF16:
+      return progressive_launch<ST, ZD, DCQ_ROUND_BF16>(pp, stream);
+    case DCQ_ROUND_INT:
+      return progressive_launch<ST, ZD, DCQ_ROUND_INT>(pp, stream);
+    default:
+      return progressive_launch<ST, ZD, DCQ_ROUND_F32>(pp, stream);
+  }
+}
+
+template <int ST>
+static int progressive_zero(const ProgressiveParams& pp, int zd, int sk, hipStream_t stream) {
+  switch (zd) {
+    case DCQ_ZERO_NONE:
+      return progressive_scale_kind<ST, DCQ_ZERO_NONE>(pp, sk, stream);
+    case DCQ_ZERO_PRE_SCALE:
+      return progressive_scale_kind<ST, DCQ_ZERO_PRE_SCALE>(pp, sk, stream);
+    default:
+      return progressive_scale_kind<ST, DCQ_ZERO_POST_SCALE>(pp, sk, stream);
+  }
+}
+
+static bool lean_int_step(const dcq_step& st) {
+  const int sk = st.scale.kind;
+  const bool scale_ok =
+      (sk == DCQ_ROUND_F32 || sk == DCQ_ROUND_F16 || sk == DCQ_ROUND_BF16 || sk == DCQ_ROUND_INT) && !st.scale.has_clamp;
+  bool zero_ok = true;
+  if (st.zero_domain == DCQ_ZERO_PRE_SCALE) zero_ok = st.zero.kind == DCQ_ROUND_INT;
+  if (st.zero_domain == DCQ_ZERO_POST_SCALE) zero_ok = st.zero.kind == sk && !st.zero.has_clamp;
+  return st.tensor.kind == DCQ_ROUND_INT && scale_ok && zero_ok;
+}
+
+}  // namespace dcq
+
+extern "C" int dcq_fake_quant_progressive(const dcq_step* first, const dcq_step* last, const void* x, int32_t storage,
+                                          int64_t rows, int64_t row_len, int64_t S, int32_t first_has_ratio,
+                                          float first_ratio, int32_t has_ratio, float ratio, float outer_lo,
+                                          float outer_hi, int32_t deq_clamp, float deq_lo, float deq_hi, void* dequant,
+                                          float* codes, float* first_scale, float* scale, float* zero,
+                                          dcq_stream_t stream) {
+  using namespace dcq;
+  DCQ_REQUIRE(first && last, DCQ_ERR_ARGUMENT, "step is NULL");
+  DCQ_REQUIRE(rows >= 0 && row_len >= 0 && S > 0, DCQ_ERR_ARGUMENT, "bad size");
+  if (rows == 0 || row_len == 0) return DCQ_OK;
+  DCQ_REQUIRE(x && first_scale, DCQ_ERR_ARGUMENT, "NULL buffer");
+  DCQ_REQUIRE(storage >= DCQ_F32 && storage <= DCQ_BF16, DCQ_ERR_ARGUMENT, "bad storage %d", storage);
+  DCQ_REQUIRE(first->zero_domain == DCQ_ZERO_NONE && first->scale.kind != DCQ_ROUND_CODEBOOK, DCQ_ERR_UNSUPPORTED,
+              "the first step must have no zero point and a scale that is not a value table");
+  DCQ_REQUIRE(lean_int_step(*last), DCQ_ERR_UNSUPPORTED,
+              "the last step must be an integer type with one float or integer scale level");
+  const int vec = storage == DCQ_F32 ? 4 : 8;
+  auto aligned = [](const void* ptr) { return ptr == nullptr || (reinterpret_cast<uintptr_t>(ptr) % 16) == 0; };
+  DCQ_REQUIRE(aligned(x) && aligned(dequant) && aligned(codes), DCQ_ERR_UNSUPPORTED, "buffers must be 16-byte aligned");
+  const int64_t lanes = S / vec;
+  DCQ_REQUIRE(S % vec == 0 && row_len % S == 0 && lanes <= 64 && (lanes & (lanes - 1)) == 0, DCQ_ERR_UNSUPPORTED,
+              "groups must be 1..64 whole 16-byte pieces (a power of two) and tile the row");
+  DCQ_REQUIRE(row_len / vec <= 256 * kMaxRowPieces, DCQ_ERR_UNSUPPORTED, "rows of more than %d values",
+              256 * kMaxRowPieces * vec);
+  ProgressiveParams pp{};
+  FusedParams& p = pp.last;
+  p.x = x;
+  p.dequant = dequant;
+  p.codes = codes;
+  p.scale_out = scale;
+  p.zero_out = zero;
+  p.G = rows * (row_len / S);
+  p.S = static_cast<int32_t>(S);
+  p.team_lanes = static_cast<int32_t>(lanes);
+  p.team_shift = __builtin_ctz(static_cast<unsigned>(lanes));
+  p.chunks = 1;
+  p.has_ratio = has_ratio;
+  p.ratio = ratio;
+  p.q_lo = last->tensor.lo;
+  p.q_hi = last->tensor.hi;
+  p.z_lo = last->zero.lo;
+  p.z_hi = last->zero.hi;
+  p.s_lo = last->scale.lo;
+  p.s_hi = last->scale.hi;
+  p.q_span = last->q_span;
+  p.q_min = last->q_min;
+  p.has_bound_min = last->has_bound_min;
+  p.has_bound_max = last->has_bound_max;
+  p.bound_min = last->bound_min;
+  p.bound_max = last->bound_max;
+  p.outer_lo = outer_lo;
+  p.outer_hi = outer_hi;
+  p.deq_clamp = deq_clamp;
+  p.deq_lo = deq_lo;
+  p.deq_hi = deq_hi;
+  pp.first_scale = first->scale;
+  pp.first_q_span = first->q_span;
+  pp.first_has_ratio = first_has_ratio;
+  pp.first_ratio = first_ratio;
+  pp.first_has_bound_max = first->has_bound_max;
+  pp.first_bound_max = first->bound_max;
+  pp.first_scale_out = first_scale;
+  pp.rows = rows;
+  pp.row_pieces = static_cast<int32_t>(row_len / vec);
+  pp.groups_per_row = static_cast<int32_t>(row_len / S);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (storage) {
+    case DCQ_F32:
+      return progressive_zero<DCQ_F32>(pp, last->zero_domain, last->scale.kind, s);
+    case DCQ_F16:
+      return progressive_zero<DCQ_F16>(pp, last->zero_domain, last->scale.kind, s);
+    default:
+      return progressive_zero<DCQ_BF16>(pp, last->zero_domain, last->scale.kind, s);
+  }
+}
+
+namespace dcq {
 
 // =============================================================================================
 // Floating-point quantization dtypes (value tables such as fp4 e2m1) without a zero point, the scale in one level or

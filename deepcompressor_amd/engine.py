@@ -159,6 +159,44 @@ def fake_quant_fused_outer(step: Step, x: torch.Tensor, outer: torch.Tensor, out
     return dq, codes, scale, zero
 
 
+def progressive_is_fusable(first: Step, last: Step, row_len: int, group: int, dtype: torch.dtype) -> bool:
+    """Whether ``dcq_fake_quant_progressive`` covers a two-step quantizer on rows of ``row_len`` values with groups of
+    ``group`` in the last step (the limits documented at its declaration)."""
+    vec = 4 if dtype == torch.float32 else 8
+    lanes = group // vec
+    if group % vec or row_len % group or lanes > 64 or lanes & (lanes - 1) or row_len // vec > 2048:
+        return False
+    if first.zero_domain != _lib.ZERO_NONE or first.scale.kind == _lib.ROUND_CODEBOOK:
+        return False
+    kinds = (_lib.ROUND_F32, _lib.ROUND_F16, _lib.ROUND_BF16, _lib.ROUND_INT)
+    if last.tensor.kind != _lib.ROUND_INT or last.scale.kind not in kinds or last.scale.has_clamp:
+        return False
+    if last.zero_domain == _lib.ZERO_PRE:
+        return last.zero.kind == _lib.ROUND_INT
+    if last.zero_domain == _lib.ZERO_POST:
+        return last.zero.kind == last.scale.kind and not last.zero.has_clamp
+    return True
+
+
+def fake_quant_progressive(first: Step, last: Step, x: torch.Tensor, group: int, outer_lo: float, outer_hi: float, *,
+                           deq_clamp: bool, deq_lo: float, deq_hi: float, first_ratio=None, ratio=None,
+                           want_dequant=True, want_codes=False):
+    """Both steps of a two-step quantizer in one pass: x[rows][row_len] -> (dequant | None, codes | None,
+    first_scale[rows], scale[G], zero[G]) with G = rows * row_len / group."""
+    _require_gpu(x)
+    rows, row_len = x.shape
+    G = rows * (row_len // group)
+    dq = torch.empty_like(x) if want_dequant else None
+    codes = torch.empty((rows, row_len), dtype=torch.float32, device=x.device) if want_codes else None
+    s0, scale, zero = _f32(rows, x.device), _f32(G, x.device), _f32(G, x.device)
+    check(lib().dcq_fake_quant_progressive(
+        C.byref(first), C.byref(last), ptr(x), storage_of(x.dtype), rows, row_len, group, int(first_ratio is not None),
+        float(first_ratio or 0.0), int(ratio is not None), float(ratio or 0.0), float(outer_lo), float(outer_hi),
+        int(deq_clamp), float(deq_lo), float(deq_hi), ptr(dq), ptr(codes), ptr(s0), ptr(scale), ptr(zero),
+        stream_of(x.device)), "dcq_fake_quant_progressive")
+    return dq, codes, s0, scale, zero
+
+
 def fake_quant_two_level(step: Step, level0: Rounding, level0_span: float, x: torch.Tensor, *, ratio=None,
                          want_dequant=True, want_codes=False):
     """Two scale levels, the first per tensor: x[G][S] -> (dequant | None, codes | None, level0[1], level1[G],

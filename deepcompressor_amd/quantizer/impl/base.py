@@ -193,6 +193,11 @@ class QuantizerImpl:
         outer = outer_range = None  # previous step: per-group divisor (in the current step's group order) and clamp
         outer_scale_data = None
         native_rtn = kernel is None or type(kernel) is QuantRtnKernel
+        if n_steps == 2 and native_rtn and round_delta is None and zero is None and scale[0] is None \
+                and scale[1] is None:
+            fused = self._quantize_two_steps_fused(tensor, dynamic_range, want_dequant, want_quant)
+            if fused is not None:
+                return fused
         for i, step_info in enumerate(info.steps):
             sinfo = step_info.scale
             n_groups = sinfo.num_groups
@@ -314,6 +319,55 @@ class QuantizerImpl:
         out = engine.smooth_fake_quant(step, x2d, groups_per_row, chan_scale, divide_first=divide_first, ratio=ratio,
                                        errors_degree=errors_degree)
         return out.view(shape) if errors_degree is None else out
+
+    def _quantize_two_steps_fused(self, tensor, dynamic_range, want_dequant, want_quant) -> QuantTensor | None:
+        """A two-step progressive quantizer whose first step has one group per row (QoQ W4: per-channel scales, then
+        groups inside the row) in ONE pass over the tensor (``dcq_fake_quant_progressive``).  None when the
+        configuration or the tensor is outside that kernel; the caller then goes step by step."""
+        info = self.info
+        first, last = info.steps
+        v0, v1 = first.tensor_view_shape, last.tensor_view_shape
+        if tensor.ndim != 2 or not tensor.is_contiguous() or len(v0) != 4 or len(v1) != 4:
+            return None
+        rows, row_len = tensor.shape
+        if tuple(v0) != (rows, 1, 1, row_len) or v1[0] != rows or v1[1] != 1 or v1[2] * v1[3] != row_len:
+            return None
+        if not (first.scale.is_single_level() and last.scale.is_single_level()) or first.scale.has_zero_point:
+            return None
+        ratios = []
+        for dyn in dynamic_range:
+            if dyn is not None and dyn.is_set():
+                if dyn.max is not None or isinstance(dyn.ratio, torch.Tensor):
+                    return None
+                ratios.append(dyn.ratio)
+            else:
+                ratios.append(None)
+        device = tensor.device
+        step0, step1 = first.scale.native(device), last.scale.native(device)
+        group = v1[3]
+        if not engine.progressive_is_fusable(step0, step1, row_len, group, tensor.dtype):
+            return None
+        outer_range = first.tensor_quant_range
+        dq, codes, s0, s1, z1 = engine.fake_quant_progressive(
+            step0, step1, tensor, group, outer_range.min, outer_range.max, deq_clamp=info.needs_dequant_saturation,
+            deq_lo=first.quant_dtype.min_value, deq_hi=first.quant_dtype.max_value, first_ratio=ratios[0],
+            ratio=ratios[1], want_dequant=want_dequant, want_codes=want_quant)
+        quantized = zero = quant_scale = None
+        if want_quant:
+            keep0, keep1 = [rows, 1, 1, 1], [rows, 1, v1[2], 1]
+            quant_scale = QuantScale()
+            quant_scale.append(QuantScale().append(s0.view(keep0)))
+            quant_scale.append(QuantScale().append(s1.view(keep1)))
+            zero = z1.view(keep1) if last.scale.has_zero_point else torch.tensor(0, dtype=torch.float32, device=device)
+            if want_dequant:  # the reference's qdata aliases its in-place float32 dequantization buffer
+                outer = s0.view(rows, 1).expand(rows, v1[2]).reshape(-1)
+                codes = engine.dequantize_groups(
+                    step1, codes.view(-1, group), s1, z1 if last.scale.has_zero_point else None, outer=outer,
+                    deq_clamp=info.needs_dequant_saturation, deq_lo=first.quant_dtype.min_value,
+                    deq_hi=first.quant_dtype.max_value, out_dtype=torch.float32)
+            quantized = codes.view(rows, row_len)
+        return QuantTensor(dequantized=dq, quantized=quantized, scale=quant_scale, zero=zero,
+                           view_shape=v1 if want_quant else None)
 
     def _quantize_last_step_fused(self, tensor, last, dyn, outer, outer_range, quant_scale, want_dequant,
                                   want_quant) -> QuantTensor | None:

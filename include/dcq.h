@@ -118,6 +118,20 @@ int dcq_fake_quant_groups_outer(const dcq_step* step, const void* x, int32_t sto
                                 float ratio, void* dequant, int32_t out_storage, float* codes, float* scale, float* zero,
                                 dcq_stream_t stream);
 
+/* dcq_fake_quant_progressive: BOTH steps of a two-step progressive quantizer in one pass over x[rows][row_len] when
+ * the first step has one group per row, no zero point and a float scale (QoQ W4: per-channel sint8 with fp16 scales,
+ * then uint4 groups of S with integer scales; quantizer/impl/base.py:211-279, examples/llm/configs/qoq-g128.yaml):
+ *     first_scale[r] = Q(|max|x[r]| * first_ratio / first->q_span|)   (0 -> 1)
+ *     the last step on clamp(x / first_scale[r], outer_lo, outer_hi) as dcq_fake_quant_groups_outer does.
+ * Limits (DCQ_ERR_UNSUPPORTED beyond them; use dcq_group_range + dcq_range_to_scale + dcq_fake_quant_groups_outer):
+ * rows of at most 2048 16-byte pieces, S a power-of-two number (<= 64) of 16-byte pieces dividing row_len, the last
+ * step an integer type with one scale level.  first_scale [rows], scale / zero [rows * row_len / S]. */
+int dcq_fake_quant_progressive(const dcq_step* first, const dcq_step* last, const void* x, int32_t storage,
+                               int64_t rows, int64_t row_len, int64_t S, int32_t first_has_ratio, float first_ratio,
+                               int32_t has_ratio, float ratio, float outer_lo, float outer_hi, int32_t deq_clamp,
+                               float deq_lo, float deq_hi, void* dequant, float* codes, float* first_scale,
+                               float* scale, float* zero, dcq_stream_t stream);
+
 /* dcq_fake_quant_groups_two_level: fake quantization with TWO scale levels, the first one per tensor -- NVFP4:
  * float4 codes in groups of 16 with float8 group scales relative to one 16-bit scale of the whole tensor
  * (quantize_scale, quantizer/impl/scale.py:20-64; examples/diffusion/configs/svdquant/nvfp4.yaml).  A reduction

@@ -219,12 +219,29 @@ def test_two_level_and_progressive_configs_take_the_single_pass_kernels(monkeypa
 
         monkeypatch.setattr(engine, name, wrapper)
 
-    for name in ("fake_quant_two_level", "fake_quant_fused_outer", "scale_level", "quantize_groups", "zero_point"):
+    for name in ("fake_quant_two_level", "fake_quant_fused_outer", "fake_quant_progressive", "scale_level",
+                 "quantize_groups", "zero_point"):
         counted(name)
     g = torch.Generator().manual_seed(1)
     w = (torch.randn(256, 1024, generator=g) * 0.02).to(torch.bfloat16).cuda()
     build_quantizer(FQ.meta["cases"]["nvfp4_g16"]).quantize(w)
     assert calls == {"fake_quant_two_level": 1}, calls
-    calls.clear()
-    build_quantizer(FQ.meta["cases"]["qoq_g128"]).quantize(w)
-    assert calls.get("fake_quant_fused_outer") == 1 and "quantize_groups" not in calls and "zero_point" not in calls, calls
+    for case in ("qoq_g128", "qoq_g128_pre"):
+        # both steps in one kernel ...
+        calls.clear()
+        one = build_quantizer(FQ.meta["cases"][case]).quantize(w, return_with_quant=True)
+        assert calls == {"fake_quant_progressive": 1}, calls
+        # ... and, where that kernel does not apply, the first step's scales followed by one pass for the last step
+        calls.clear()
+        monkeypatch.setattr(engine, "progressive_is_fusable", lambda *a, **k: False)
+        two = build_quantizer(FQ.meta["cases"][case]).quantize(w, return_with_quant=True)
+        monkeypatch.undo()
+        for name in ("fake_quant_two_level", "fake_quant_fused_outer", "fake_quant_progressive", "scale_level",
+                     "quantize_groups", "zero_point"):
+            counted(name)
+        assert calls.get("fake_quant_fused_outer") == 1 and "quantize_groups" not in calls, calls
+        assert torch.equal(one.data, two.data) and torch.equal(one.qdata, two.qdata)
+        assert torch.equal(one.zero, two.zero)
+        assert torch.equal(one.scale.data, two.scale.data)
+        for level in (0, 1):
+            assert torch.equal(one.scale.get_child(level).data, two.scale.get_child(level).data)
