@@ -186,6 +186,32 @@ def stage_rooflines(device, weights, objs) -> list:
                 "frac": big_bytes / t_big / 8e12, "frac_of_measured_copy_6290": big_bytes / t_big / 6.29e12,
                 "algorithmic_bytes": big_bytes, "traffic": pmc.get("hbm_bytes"), "avg_launch_ms": t_big * 1e3,
                 "valu_insts_per_launch": pmc.get("avg_per_launch", {}).get("SQ_INSTS_VALU")})
+    # The other two weight formats of the reference's examples, same tensor: NVFP4 (float4 in groups of 16, float8
+    # group scales under one per-tensor scale: a max|x| reduction, then one pass) and QoQ W4 (per-row fp16 scales,
+    # then uint4 groups of 128 with integer scales: one pass).  Algorithmic bytes: every read and write the format
+    # needs (NVFP4 reads the tensor twice, the per-tensor scale depends on all of it).
+    from deepcompressor_amd.data.dtype import QuantDataType
+    from deepcompressor_amd.data.zero import ZeroPointDomain
+    from deepcompressor_amd.quantizer import ProgressiveQuantizerConfig, QuantizerConfig
+
+    n_big = big.numel()
+    nvfp4 = Quantizer(QuantizerConfig(dtype=QuantDataType.from_str("sfp4_e2m1_all"), zero_point=None,
+                                      group_shapes=((-1, -1), (1, 16)),
+                                      scale_dtypes=(None, QuantDataType.from_str("sfp8_e4m3_nan"))), key="nvfp4")
+    qoq = Quantizer(ProgressiveQuantizerConfig(
+        dtype=QuantDataType.from_str("uint4"), zero_point=ZeroPointDomain.PostScale, group_shapes=((1, -1), (1, 128)),
+        scale_dtypes=(torch.float16, QuantDataType.from_str("sint8")),
+        intermediate_dtypes=(QuantDataType.from_str("sint8"),), intermediate_levels=(0,)), key="qoq")
+    for label, quantizer, nbytes in (
+            ("tensor_absmax_kernel + fused_table_kernel (NVFP4 g16: two reads, one write, two float32 scales per group)",
+             nvfp4, n_big * 6 + (n_big // 16) * 8),
+            ("progressive_int_kernel (QoQ W4 g128: per-row fp16 scale and uint4 groups with integer scales, one pass)",
+             qoq, n_big * 4 + (n_big // 128) * 8 + big.shape[0] * 4)):
+        t = timed(lambda: quantizer.quantize(big), 10)
+        out.append({"kernel": label, "bound": "hbm", "shape": list(big.shape), "achieved": nbytes / t / 1e9,
+                    "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 8e12, "algorithmic_bytes": nbytes,
+                    "traffic": None, "avg_launch_ms": t * 1e3,
+                    "note": "duration of the whole quantize() call (all its launches)"})
     del big
     w = weights["gate_proj"]
     t_fq = timed(lambda: q.quantize(w), 20)
@@ -218,6 +244,98 @@ def stage_rooflines(device, weights, objs) -> list:
                                  "(packed two-value float32 instructions occupy the pipe for 4 cycles, twice the "
                                  "2-cycle issue slot the second figure assumes)",
                          "insts_per_candidate_eval": insts * 64 / (n * 101) if insts else None}})
+    return out
+
+
+def other_configs(device) -> list:
+    """Wall time of one unit of the other workloads the baseline file lists (they are parity-test cases; the headline
+    value above is the GPTQ one).  Synthetic inputs resident in HBM, one warm-up call, then the mean of a few calls
+    bracketed by device synchronisation."""
+    import torch.nn as nn
+
+    from deepcompressor_amd.calib import calibrate_dynamic_range
+    from deepcompressor_amd.calib.config import (DynamicRangeCalibConfig, SearchBasedCalibGranularity,
+                                                 SearchBasedCalibObjective, SearchBasedCalibStrategy, SmoothCalibConfig,
+                                                 SmoothSpanMode)
+    from deepcompressor_amd.calib.smooth import SmoothLinearCalibrator
+    from deepcompressor_amd.data.cache import TensorCache, TensorsCache
+    from deepcompressor_amd.data.common import TensorType
+    from deepcompressor_amd.data.dtype import QDType, QuantDataType
+    from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
+    from deepcompressor_amd.data.zero import ZeroPointDomain
+    from deepcompressor_amd.quantizer import ProgressiveQuantizerConfig, Quantizer, QuantizerConfig
+    from deepcompressor_amd.quantizer.config.lowrank import QuantLowRankConfig
+
+    def wall(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    g = torch.Generator(device=device).manual_seed(99)
+    rand = lambda *shape: torch.randn(*shape, generator=g, device=device)  # noqa: E731
+    out = []
+    # configs[0]: sint4 g128 fake-quant + range-ratio search on a 4096 x 4096 bf16 linear
+    w = (rand(4096, 4096) * 0.02).to(torch.bfloat16)
+    q0 = Quantizer(QuantizerConfig(dtype=QDType.sint4, zero_point=None, group_shapes=((1, 128),),
+                                   scale_dtypes=(torch.float16,)), key="c0")
+    rcfg = DynamicRangeCalibConfig(objective=SearchBasedCalibObjective.TensorError,
+                                   strategy=SearchBasedCalibStrategy.GridSearch,
+                                   granularity=SearchBasedCalibGranularity.Group, degree=2, ratio=1.0, max_shrink=0.2,
+                                   max_expand=1.0, num_grids=80)
+
+    def c0():
+        dyn = calibrate_dynamic_range(TensorType.Weights, rcfg, True, q0, modules=[None], activations=None,
+                                      weights=[nn.Parameter(w, requires_grad=False)])
+        return q0.quantize(w, dynamic_range=dyn)
+
+    t = wall(c0, 5)
+    out.append({"config": "configs[0]: sint4 g128 range-ratio search (81 candidates) + fake-quant, 4096 x 4096 bf16",
+                "ms": t * 1e3, "Gparam_per_s": w.numel() / t / 1e9})
+    # configs[2]: QoQ W4 (per-channel sint8 under fp16 scales, then uint4 g128 with int8 scales) on the 7 linears of a
+    # Llama-3-8B layer
+    qoq = Quantizer(ProgressiveQuantizerConfig(
+        dtype=QuantDataType.from_str("uint4"), zero_point=ZeroPointDomain.PostScale, group_shapes=((1, -1), (1, 128)),
+        scale_dtypes=(torch.float16, QuantDataType.from_str("sint8")),
+        intermediate_dtypes=(QuantDataType.from_str("sint8"),), intermediate_levels=(0,)), key="c2")
+    layer = [(rand(r, c) * 0.02).to(torch.float16) for _, r, c, _ in LLAMA3_8B_LAYER]
+    t = wall(lambda: [qoq.quantize(x) for x in layer], 5)
+    out.append({"config": "configs[2]: QoQ W4 progressive fake-quant of the 7 linears of one Llama-3-8B layer, fp16",
+                "ms": t * 1e3, "Gparam_per_s": PARAMS_PER_LAYER / t / 1e9})
+    del layer
+    # configs[3]: SVDQuant W4 (sint4 g64) with a rank-32 low-rank branch on a FLUX.1-dev 3072 x 3072 linear
+    svd = Quantizer(QuantizerConfig(dtype=QDType.sint4, zero_point=None, group_shapes=((1, 64),),
+                                    scale_dtypes=(torch.float16,)), key="c3", low_rank=QuantLowRankConfig(rank=32))
+    wf = (rand(3072, 3072) * 0.02).to(torch.bfloat16)
+    t = wall(lambda: svd.quantize_with_low_rank([wf]), 3)
+    out.append({"config": "configs[3]: SVDQuant sint4 g64 + rank-32 branch (SVD, residual fake-quant), 3072 x 3072 bf16",
+                "ms": t * 1e3, "Gparam_per_s": wf.numel() / t / 1e9})
+    del wf
+    # configs[4]: SAM2 Hiera-L fc1 (1152 -> 4608) W8A8 per channel / per token, per-channel smoothing search with
+    # alpha = 0.5, beta = -2, 20 grids (39 candidates) scored on the layer's outputs, 4096 tokens
+    fc1 = nn.Linear(1152, 4608, bias=True, device=device, dtype=torch.float32)
+    fc1.weight.data = rand(4608, 1152) * 0.03
+    gains = torch.exp(rand(1152) * 1.2)
+    xs = [rand(1, 1024, 1152) * gains for _ in range(4)]
+    cache = TensorsCache(TensorCache(xs, channels_dim=-1, reshape=LinearReshapeFn(), num_cached=4, num_total=4,
+                                     num_samples=4, orig_device=device))
+    w8 = QuantizerConfig(dtype=QDType.sint8, zero_point=None, group_shapes=((1, -1),), scale_dtypes=(None,))
+    wq, xq = Quantizer(w8, key="w"), Quantizer(w8, channels_dim=-1, key="x")
+    scfg = SmoothCalibConfig(spans=[(SmoothSpanMode.AbsMax, SmoothSpanMode.AbsMax)], alpha=0.5, beta=-2, num_grids=20,
+                             strategy=SearchBasedCalibStrategy.GridSearch,
+                             objective=SearchBasedCalibObjective.OutputsError,
+                             granularity=SearchBasedCalibGranularity.Layer)
+
+    def c4():
+        return SmoothLinearCalibrator(scfg, wq, xq).calibrate(x_wgts=[fc1.weight], x_acts=cache, x_mods=[fc1],
+                                                              eval_inputs=cache, eval_module=fc1, eval_kwargs={})
+
+    t = wall(c4, 3)
+    out.append({"config": "configs[4]: Hiera-L fc1 1152 -> 4608 W8A8 smoothing search, 39 candidates, 4096 tokens, f32",
+                "ms": t * 1e3, "candidates_per_s": 39 / t})
     return out
 
 
@@ -337,6 +455,8 @@ def main() -> None:
         }
         if world == 1:
             line["rooflines"] = stage_rooflines(device, weights, objs)
+            del weights, caches
+            line["other_configs"] = other_configs(device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
