@@ -137,7 +137,8 @@ def _all_gather_ragged(parts: list[torch.Tensor], mine: torch.Tensor, rank: int,
         dist.broadcast(parts[r], src=r)
 
 
-def run_on_streams(jobs, device: torch.device | str | None = None, priorities: list[int] | None = None) -> list:
+def run_on_streams(jobs, device: torch.device | str | None = None, priorities: list[int] | None = None,
+                   after: list | None = None) -> list:
     """Run independent jobs concurrently on ONE GPU, each on its own HIP stream driven by its own host thread, and
     return their results in order.
 
@@ -151,7 +152,10 @@ def run_on_streams(jobs, device: torch.device | str | None = None, priorities: l
 
     Every stream first waits for the work already queued on the caller's current stream (the inputs), and the
     caller's stream waits for every job's stream before this returns, so results can be used as usual afterwards.
-    ``priorities``: optional HIP stream priority per job (lower number = higher priority)."""
+    ``priorities``: optional HIP stream priority per job (lower number = higher priority).  ``after``: optional
+    event per job, recorded on the caller's stream; job i's stream then waits for that event only, not for everything
+    queued on the caller's stream -- a job whose inputs are ready early starts while the caller's stream is still
+    producing the inputs of the others."""
     import threading
 
     jobs = list(jobs)
@@ -166,7 +170,10 @@ def run_on_streams(jobs, device: torch.device | str | None = None, priorities: l
     def work(i: int) -> None:
         try:
             torch.cuda.set_device(dev)
-            streams[i].wait_stream(caller)
+            if after is not None and after[i] is not None:
+                streams[i].wait_event(after[i])
+            else:
+                streams[i].wait_stream(caller)
             with torch.inference_mode(inference), torch.set_grad_enabled(grad_mode), torch.cuda.stream(streams[i]):
                 results[i] = jobs[i]()
         except BaseException as exc:  # noqa: BLE001 -- re-raised in the caller's thread

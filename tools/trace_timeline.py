@@ -1,25 +1,50 @@
-"""Per-queue timeline of one bench step from a rocprofv3 kernel trace: python tools/trace_timeline.py <kernel_trace.csv>
-Prints, for the last step (after the last big gap), each queue's busy span and its top kernels."""
-import csv, sys, collections
-rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows:
-    r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-rows.sort(key=lambda r: r["s"])
-# last step = from the last syrk launch on C=14336 (the longest kernel) onwards
-syrk = [r for r in rows if "syrk_kernel" in r["Kernel_Name"] and r["e"] - r["s"] > 30e6]
+"""Per-stream timeline of the last bench step from a rocprofv3 kernel trace (rocpd .db):
+    python tools/trace_timeline.py <results.db>
+For each stream: busy span, kernel time, and the sequence of phases (runs of launches of the same kernel family)."""
+import collections
+import sqlite3
+import sys
+
+con = sqlite3.connect(sys.argv[1])
+rows = [dict(name=n, s=s, e=e, stream=st) for n, s, e, st in
+        con.execute("select name, start, end, stream_id from kernels order by start")]
+syrk = [r for r in rows if "syrk_kernel" in r["name"] and r["e"] - r["s"] > 30e6]
 t0 = syrk[-1]["s"]
 step = [r for r in rows if r["s"] >= t0 - 5e6]
 tend = max(r["e"] for r in step)
 print(f"step span {(tend - t0) / 1e6:.1f} ms, {len(step)} kernels")
-byq = collections.defaultdict(list)
+
+
+def family(name: str) -> str:
+    for key in ("syrk", "transpose_pad", "range_search", "panel", "gemm_f32", "trsm", "sweep", "fused_int", "lazy",
+                "symmetr", "damp", "diag", "permute", "gather"):
+        if key in name:
+            return key
+    return name.split("(")[0][-40:]
+
+
+by = collections.defaultdict(list)
 for r in step:
-    byq[r["Queue_Id"]].append(r)
-for q, rs in sorted(byq.items(), key=lambda kv: kv[1][0]["s"]):
+    by[r["stream"]].append(r)
+for st, rs in sorted(by.items(), key=lambda kv: kv[1][0]["s"]):
     busy = sum(r["e"] - r["s"] for r in rs)
-    print(f"queue {q}: first {(rs[0]['s'] - t0) / 1e6:7.2f} ms  last end {(max(r['e'] for r in rs) - t0) / 1e6:7.2f} ms  "
+    print(f"stream {st}: first {(rs[0]['s'] - t0) / 1e6:7.2f}  last end {(max(r['e'] for r in rs) - t0) / 1e6:7.2f} ms  "
           f"kernel time {busy / 1e6:7.2f} ms  launches {len(rs)}")
-    agg = collections.Counter()
+    # phases: merge consecutive launches whose families were seen within the same 2 ms window
+    seg = None
+    segs = []
     for r in rs:
-        agg[r["Kernel_Name"][:60]] += r["e"] - r["s"]
-    for name, t in agg.most_common(5):
-        print(f"      {t / 1e6:7.2f} ms  {name}")
+        f = family(r["name"])
+        if seg is not None and (f in seg["fams"] or r["s"] - seg["e"] < 0.3e6 and len(seg["fams"]) < 6):
+            seg["fams"][f] += r["e"] - r["s"]
+            seg["e"] = max(seg["e"], r["e"])
+            seg["n"] += 1
+        else:
+            seg = dict(s=r["s"], e=r["e"], n=1, fams=collections.Counter({f: r["e"] - r["s"]}))
+            segs.append(seg)
+    for g in segs:
+        if g["e"] - g["s"] < 0.5e6:
+            continue
+        top = ", ".join(f"{k} {v / 1e6:.1f}" for k, v in g["fams"].most_common(4))
+        print(f"      {(g['s'] - t0) / 1e6:7.2f} -> {(g['e'] - t0) / 1e6:7.2f} ms  {g['n']:5d} launches  busy "
+              f"{sum(g['fams'].values()) / 1e6:6.1f} ms  [{top}]")
