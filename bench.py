@@ -71,78 +71,53 @@ def build_objects():
     return Quantizer, qcfg, rcfg, gcfg
 
 
-def quantize_layer(weights, caches, objs, syrk_events=None, streams: int = 1):
-    """The hot path for one layer; returns the dequantized weights (kept so nothing is optimised away).
+def stage_config():
+    """examples/llm/configs/gptq.yaml of the reference with enable_calib_range = true ("GPTQ-R") as the weight
+    stage's config."""
+    from deepcompressor_amd.app import LlmWeightQuantizerConfig
+    from deepcompressor_amd.calib import (SearchBasedCalibGranularity, SearchBasedCalibObjective,
+                                          SearchBasedCalibStrategy)
+    from deepcompressor_amd.calib.config import SkipBasedDynamicRangeCalibConfig
+    from deepcompressor_amd.data.dtype import QDType
+    from deepcompressor_amd.data.zero import ZeroPointDomain
+    from deepcompressor_amd.quantizer import QuantGptqConfig
 
-    ``streams`` > 1: the linears are grouped by the activations they share (q/k/v, o, gate/up, down); the groups
-    are independent and run concurrently, one HIP stream and host thread each."""
+    return LlmWeightQuantizerConfig(
+        dtype=QDType.uint4, zero_point=ZeroPointDomain.PostScale, group_shapes=((1, 128),), scale_dtypes=(torch.float16,),
+        calib_range=SkipBasedDynamicRangeCalibConfig(
+            degree=2.4, objective=SearchBasedCalibObjective.TensorError, strategy=SearchBasedCalibStrategy.GridSearch,
+            granularity=SearchBasedCalibGranularity.Group, max_shrink=0.2, max_expand=1.0, num_grids=100),
+        kernel_gptq=QuantGptqConfig(damp_percentage=0.01, block_size=128, num_inv_tries=250, hessian_block_size=512))
+
+
+def quantize_layer(weights, caches, config, syrk_events=None, streams: int = 1):
+    """The hot path for one layer through the weight stage of the package (the reference's
+    app/llm/quant/weight.py:24-105): range search, then GPTQ fed by the cached inputs, for the 7 linears.  Returns the
+    modules holding the dequantized weights (kept so nothing is optimised away)."""
     import torch.nn as nn
 
     from deepcompressor_amd import _lib
-    from deepcompressor_amd.calib import calibrate_dynamic_range
-    from deepcompressor_amd.data.common import TensorType
-    from deepcompressor_amd.parallel import run_on_streams
-    from deepcompressor_amd.quantizer.kernel import gptq as gptq_mod
+    from deepcompressor_amd.app import LinearEntry, quantize_layer_weights
+    from deepcompressor_amd.data.cache import IOTensorsCache, TensorsCache
 
-    Quantizer, qcfg, rcfg, gcfg = objs
+    entries, layer_cache = [], {}
+    for name, r, c, key in LLAMA3_8B_LAYER:
+        w = weights[name]
+        module = nn.Linear(c, r, bias=False, device="meta")
+        module.weight = nn.Parameter(w, requires_grad=False)  # the stage replaces .data, `weights` keeps the original
+        entries.append(LinearEntry(key=name, name=f"layer.{name}", module=module))
+        layer_cache[f"layer.{name}"] = IOTensorsCache(inputs=TensorsCache(caches[key]))
 
-    def profiled_hessian(key, c):
+    def hessian_hook(channels):
         if syrk_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             # torch creates the HIP event lazily on first record; record once so the handles exist
             e0.record(), e1.record()
             _lib.lib().dcq_profile_next_hessian(e0.cuda_event, e1.cuda_event)
-            syrk_events.append((e0, e1, c))
-        gptq_mod.prepare_hessians([caches[key]], weights["q_proj"].device)
+            syrk_events.append((e0, e1, channels))
 
-    def run_group(members):
-        out = {}
-        for name, _, c, key in members:
-            w = weights[name]
-            q = Quantizer(qcfg, key=name, kernel=gcfg, develop_dtype=torch.float32)
-            ranges = calibrate_dynamic_range(TensorType.Weights, rcfg, True, q, modules=[None], activations=None,
-                                             weights=[nn.Parameter(w, requires_grad=False)])
-            out[name] = q.quantize(w, dynamic_range=ranges[0], inputs=caches[key]).data
-        return out
-
-    groups: dict[str, list] = {}
-    for row in LLAMA3_8B_LAYER:
-        groups.setdefault(row[3], []).append(row)
-    try:
-        if streams <= 1:
-            out = {}
-            for key, members in groups.items():
-                profiled_hessian(key, members[0][2])
-                out.update(run_group(members))
-                gptq_mod.clear_hessian_cache()
-            return out
-        # phase 1: the Hessians, one after the other, each launch with the whole chip to itself; phase 2: the
-        # latency-bound rest (search, inverse factor, sweeps) of the independent groups side by side.
-        # longest pipeline first (cost ~ C^3 for the factor, R C^2 for the sweeps)
-        order = sorted(groups.values(), key=lambda ms: -(ms[0][2] ** 2) * (ms[0][2] + sum(m[1] for m in ms)))
-        ready = {}
-        for ms in order:
-            profiled_hessian(ms[0][3], ms[0][2])
-            ready[ms[0][3]] = torch.cuda.Event()
-            ready[ms[0][3]].record()
-        buckets = [order[i::streams] for i in range(min(streams, len(order)))]
-
-        def run_bucket(bucket):
-            parts = []
-            for ms in bucket:  # a group starts as soon as ITS Hessian is there; later Hessians overlap with it
-                torch.cuda.current_stream().wait_event(ready[ms[0][3]])
-                parts.append(run_group(ms))
-            return parts
-
-        results = run_on_streams([lambda b=b: run_bucket(b) for b in buckets],
-                                 after=[ready[b[0][0][3]] for b in buckets])
-        out = {}
-        for bucket in results:
-            for part in bucket:
-                out.update(part)
-        return out
-    finally:
-        gptq_mod.clear_hessian_cache()
+    quantize_layer_weights(entries, config, {}, layer_cache=layer_cache, streams=streams, hessian_hook=hessian_hook)
+    return [e.module for e in entries]
 
 
 PMC_FILE = os.path.join(ROOT, "profiles", "r2_stage_pmc.json")
@@ -413,15 +388,16 @@ def main() -> None:
     from deepcompressor_amd.parallel import barrier_and_max
 
     objs = build_objects()
+    config = stage_config()
     weights, caches = make_layer(device, args.tokens, seed=1234 + rank)
     for _ in range(args.warmup):
-        quantize_layer(weights, caches, objs, streams=args.streams)
+        quantize_layer(weights, caches, config, streams=args.streams)
     torch.cuda.synchronize()
     barrier_and_max(0.0, world, device)
     syrk_events: list = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        outputs = quantize_layer(weights, caches, objs, syrk_events, streams=args.streams)
+        outputs = quantize_layer(weights, caches, config, syrk_events, streams=args.streams)
     torch.cuda.synchronize()
     elapsed = barrier_and_max(time.perf_counter() - t0, world, device)
     del outputs

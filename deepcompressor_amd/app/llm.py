@@ -174,16 +174,27 @@ class LinearEntry:
 def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQuantizerConfig,
                            quantizer_state_dict: dict[str, tp.Any],
                            layer_cache: dict[str, IOTensorsCache] | None = None,
-                           return_with_scale_state_dict: bool = False, develop_dtype: torch.dtype = torch.float32
+                           return_with_scale_state_dict: bool = False, develop_dtype: torch.dtype = torch.float32,
+                           streams: int = 1, hessian_hook: tp.Callable[[int], None] | None = None
                            ) -> dict[str, torch.Tensor | float | None]:
     """app/llm/quant/weight.py:24-105.  Pass 1 calibrates the range of every linear that has no entry in
     ``quantizer_state_dict`` yet (and stores it there); pass 2 reloads each range, quantizes the weight with the
     configured kernel (GPTQ when set, fed by the linear's cached inputs) and writes the dequantized weight back into
-    the module.  Returns the scale state dict when asked for."""
+    the module.  Returns the scale state dict when asked for.
+
+    ``streams`` > 1 (no counterpart in the reference, same results): with the GPTQ kernel, the linears are grouped by
+    the cached inputs they share (q/k/v, gate/up ...); the groups' Hessians are computed one after the other on the
+    caller's stream, each with the whole chip, largest pipeline first, and every group's searches, inverse factor and
+    sweeps start on a stream of their own as soon as that group's Hessian is there.  ``hessian_hook(channels)`` is
+    called right before each of those Hessians is enqueued (a measurement hook)."""
     from ..quantizer.kernel.gptq import clear_hessian_cache
 
+    layer_cache = layer_cache or {}
     try:
-        return _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache or {},
+        if streams > 1 and layer_cache and config.enabled_gptq and len(entries) > 1:
+            return _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, layer_cache,
+                                                      return_with_scale_state_dict, develop_dtype, streams, hessian_hook)
+        return _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache,
                                        return_with_scale_state_dict, develop_dtype)
     finally:
         # the GPTQ kernel memoises the Hessian (and its inverse factor) of the last activation cache together with a
@@ -191,8 +202,61 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
         clear_hessian_cache()
 
 
+def _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, layer_cache, return_with_scale_state_dict,
+                                       develop_dtype, streams, hessian_hook) -> dict[str, torch.Tensor | float | None]:
+    from ..parallel import run_on_streams
+    from ..quantizer.kernel import gptq as gptq_mod
+
+    device = entries[0].module.weight.device
+    groups: dict[tp.Any, list[LinearEntry]] = {}
+    for e in entries:
+        groups.setdefault(gptq_mod.inputs_key(layer_cache[e.name].inputs.front(), device), []).append(e)
+
+    def cost(members):  # ~ C^3 for the inverse factor + R C^2 for the sweeps
+        c = members[0].module.in_features
+        return c * c * (c + sum(m.module.out_features for m in members))
+
+    order = sorted(groups.values(), key=cost, reverse=True)
+    ready = []
+    for members in order:
+        if hessian_hook is not None:
+            hessian_hook(members[0].module.in_features)
+        gptq_mod.prepare_hessians([layer_cache[members[0].name].inputs.front()], device)
+        ready.append(torch.cuda.Event())
+        ready[-1].record()
+    buckets = [list(range(i, len(order), streams)) for i in range(min(streams, len(order)))]
+
+    pending: list = []  # host copies of the searched ranges and zeros, taken when every pipeline has been enqueued
+
+    def run_bucket(indices):
+        parts = []
+        for i in indices:
+            torch.cuda.current_stream().wait_event(ready[i])
+            parts.append(_quantize_layer_weights(order[i], config, quantizer_state_dict, layer_cache,
+                                                 return_with_scale_state_dict, develop_dtype, host_copies=pending))
+        return parts
+
+    results = run_on_streams([lambda b=b: run_bucket(b) for b in buckets], device=device,
+                             after=[ready[b[0]] for b in buckets])
+    for copy in pending:
+        copy()
+    merged: dict[str, torch.Tensor | float | None] = {}
+    for bucket in results:
+        for part in bucket:
+            merged.update(part)
+    # keys in the order the serial stage produces them
+    names = [f"{e.name}.weight." for e in entries]
+    return dict(sorted(merged.items(), key=lambda kv: next((i for i, n in enumerate(names) if kv[0].startswith(n)),
+                                                          len(names))))
+
+
 def _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache, return_with_scale_state_dict,
-                            develop_dtype) -> dict[str, torch.Tensor | float | None]:
+                            develop_dtype, host_copies: list | None = None) -> dict[str, torch.Tensor | float | None]:
+    # Ranges searched here stay on the device for the second pass; their host copies for ``quantizer_state_dict``
+    # (the contents of wgts.pt) are taken after the last kernel of the stage is enqueued, so that no search is waited
+    # for before the work behind it is queued.  ``host_copies``: a list that receives those pending copies as
+    # callables instead (the caller runs them once all of its pipelines are done).
+    searched: dict[str, LlmWeightQuantizer] = {}
     for e in entries:
         assert isinstance(e.module, nn.Linear)
         quantizer = LlmWeightQuantizer(config, develop_dtype=develop_dtype, key=e.key)
@@ -203,14 +267,16 @@ def _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache, 
                 eval_inputs=layer_cache[eval_name].inputs if layer_cache else None,
                 # without cached activations only a search on the weight itself can run: no evaluation module then
                 eval_module=(e.eval_module or e.module) if layer_cache else None, eval_kwargs=e.eval_kwargs)
-            quantizer_state_dict[e.name] = quantizer.state_dict()
+            searched[e.name] = quantizer
     scale_state_dict: dict[str, torch.Tensor | float | None] = {}
+    zeros: list[tuple[str, torch.Tensor]] = []
     for e in entries:
-        quantizer = LlmWeightQuantizer(config, develop_dtype=develop_dtype, key=e.key)
+        quantizer = searched.get(e.name) or LlmWeightQuantizer(config, develop_dtype=develop_dtype, key=e.key)
         if not quantizer.is_enabled():
             continue
         param_name = f"{e.name}.weight"
-        quantizer.load_state_dict(quantizer_state_dict[e.name], device=e.module.weight.device)
+        if e.name not in searched:
+            quantizer.load_state_dict(quantizer_state_dict[e.name], device=e.module.weight.device)
         result = quantizer.quantize(e.module.weight.data,
                                     inputs=layer_cache[e.name].inputs.front() if layer_cache else None,
                                     return_with_dequant=True, return_with_quant=return_with_scale_state_dict)
@@ -218,8 +284,19 @@ def _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache, 
         if return_with_scale_state_dict:
             scale_state_dict.update(result.scale.state_dict(f"{param_name}.scale"))
             zero_name = "scaled_zero" if config.zero_domain is ZeroPointDomain.PostScale else "zero"
-            zero = result.zero
-            scale_state_dict[f"{param_name}.{zero_name}"] = zero.to("cpu") if isinstance(zero, torch.Tensor) else zero
+            scale_state_dict[f"{param_name}.{zero_name}"] = result.zero
+            if isinstance(result.zero, torch.Tensor):
+                zeros.append((f"{param_name}.{zero_name}", result.zero))
+    def copy_to_host() -> None:
+        for name, quantizer in searched.items():
+            quantizer_state_dict[name] = quantizer.state_dict()
+        for key, zero in zeros:
+            scale_state_dict[key] = zero.to("cpu")
+
+    if host_copies is None:
+        copy_to_host()
+    else:
+        host_copies.append(copy_to_host)
     return scale_state_dict
 
 

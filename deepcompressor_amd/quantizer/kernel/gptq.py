@@ -162,6 +162,11 @@ def _inputs_key(inputs: TensorCache, device: torch.device):
             tuple((id(t), t.data_ptr(), tuple(t.shape), t.dtype, _version_of(t)) for t in inputs.data))
 
 
+def inputs_key(inputs: TensorCache, device: torch.device):
+    """Two caches with the same key hold the same tensors and share one Hessian (valid while the tensors are alive)."""
+    return _inputs_key(inputs, device)
+
+
 def hessian_of(inputs: TensorCache, device: torch.device) -> torch.Tensor:
     """2 / num_samples * sum_x x^T x over the cache (float32, C x C), memoised for the last cache seen."""
     key = _inputs_key(inputs, device)

@@ -160,6 +160,37 @@ def test_weight_stage_with_gptq_kernel():
         assert err_gptq < err_rtn, (e.name, float(err_gptq), float(err_rtn))
 
 
+def test_weight_stage_on_streams_equals_the_serial_stage():
+    """``streams`` > 1 (Hessians up front, one pipeline per group of linears that share their cached inputs, each on
+    its own HIP stream) changes the schedule only: scales, zeros and GPTQ-updated weights are bit-equal to the serial
+    stage's, and the scale state dict has the same keys in the same order."""
+    tag = "gptq_r_rtn"
+    m = LS.meta[tag]
+    g = torch.Generator().manual_seed(11)
+    serial, piped = build_layer(tag), build_layer(tag)
+    shared = {}
+    cache = {}
+    for e in serial:
+        c = e.module.in_features
+        if c not in shared:  # linears with the same width share one cached input, as q / k / v do
+            x = (torch.randn(4, 256, c, generator=g) * torch.exp(0.7 * torch.randn(c, generator=g))).to(torch.float16).cuda()
+            shared[c] = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_cached=1, num_total=1,
+                                    num_samples=1024, orig_device=x.device)
+        cache[e.name] = IOTensorsCache(inputs=TensorsCache(shared[c]))
+    config = stage_config(m["case"], kernel_gptq=QuantGptqConfig())
+    seen = []
+    want = quantize_layer_weights(serial, config, {}, layer_cache=cache, return_with_scale_state_dict=True)
+    got = quantize_layer_weights(piped, config, {}, layer_cache=cache, return_with_scale_state_dict=True, streams=3,
+                                 hessian_hook=seen.append)
+    assert sorted(seen, reverse=True) == seen and len(seen) == len(shared), seen
+    assert list(got) == list(want)
+    for key in want:
+        a, b = want[key], got[key]
+        assert torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b, key
+    for a, b in zip(serial, piped):
+        assert torch.equal(a.module.weight.data, b.module.weight.data), a.name
+
+
 def test_activation_stage_calibrates_reloads_and_hooks():
     """smoothquant-static style: dynamic per-token int8 inputs (nothing to store) and static per-tensor int8 outputs
     (the stored range is the largest magnitude in the cache); acts.pt entries reload into the same behaviour."""
