@@ -204,7 +204,7 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
 
 def _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, layer_cache, return_with_scale_state_dict,
                                        develop_dtype, streams, hessian_hook) -> dict[str, torch.Tensor | float | None]:
-    from ..parallel import run_on_streams
+    from ..parallel import assign_by_cost, run_on_streams
     from ..quantizer.kernel import gptq as gptq_mod
 
     device = entries[0].module.weight.device
@@ -224,7 +224,8 @@ def _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, la
         gptq_mod.prepare_hessians([layer_cache[members[0].name].inputs.front()], device)
         ready.append(torch.cuda.Event())
         ready[-1].record()
-    buckets = [list(range(i, len(order), streams)) for i in range(min(streams, len(order)))]
+    # longest pipeline first, the rest dealt to the least loaded stream (each list ascending = order of readiness)
+    buckets = [b for b in assign_by_cost([float(cost(members)) for members in order], min(streams, len(order))) if b]
 
     pending: list = []  # host copies of the searched ranges and zeros, taken when every pipeline has been enqueued
 

@@ -230,10 +230,16 @@ static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s) {
 }
 
 // =============================================================================================
-// Diagonal block.  Gauss-Jordan on the augmented block [A | I] in registers: after the 128 elimination steps the
-// left part is R11 (upper, R11^T R11 = A) and the right part is R11^-T, whose transpose X11 = R11^-1 is written
-// into the inverse matrix.  One workgroup of 16 x 16 threads, each owning an 8 x 8 sub-block of both parts; per
-// step the pivot row travels through a double-buffered LDS row (one barrier per step).
+// Diagonal block.  Cholesky elimination on the augmented block [A | I] in registers: after the 128 pivots the left
+// part is R11 (upper, R11^T R11 = A) and the right part is R11^-T, whose transpose X11 = R11^-1 is written into the
+// inverse matrix.  One workgroup of 2 x 16 x 16 threads, each owning an 8 x 8 sub-block of one part.
+//
+// The pivots are taken 8 at a time (the 8 rows of one thread row), with two barriers per group instead of one per
+// pivot.  With D the group's 8 x 8 diagonal block and D = L L^T:
+//   1. the thread that holds D factors it and forms W = L^-1 (8 x 8, lower) in registers          -> LDS
+//   2. the threads of the group's row replace their rows by W x rows (the rows' final values)      -> LDS
+//   3. every thread below subtracts (column r of the final rows) x (final rows) from its rows r.
+// The strict lower triangle of the left part is never used (it collects garbage and is written as zero).
 // info: 1-based global index of the first non-positive pivot (atomicMin: the earliest failure wins); the
 // arithmetic then continues on NaNs, which is harmless (no data-dependent addressing).
 // =============================================================================================
@@ -242,9 +248,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(kPanelThreads) void panel_factor_kernel(float* a, int64_t lda, float* x, int64_t ldx,
                                                                       int32_t* info, int32_t index_base) {
-  __shared__ __align__(16) float rowbuf[2][2][kNb];  // [step parity][A part | Y part][column]
+  __shared__ __align__(16) float rows[8][2][kNb];  // the group's final rows: [row][A part | Y part][column]
+  __shared__ __align__(16) float wmat[8][8];       // W = L^-1 of the group's diagonal block
   const int tid = threadIdx.x, tx = tid & 15, ty = (tid >> 4) & 15;
-  const int part = tid >> 8;  // waves 0-3 hold the A part, waves 4-7 the Y part: no wave executes both updates
+  const int part = tid >> 8;  // waves 0-3 hold the A part, waves 4-7 the Y part
   f32x2 Z[8][4];
 #pragma unroll
   for (int ii = 0; ii < 8; ++ii) {
@@ -258,53 +265,85 @@ __global__ __launch_bounds__(kPanelThreads) void panel_factor_kernel(float* a, i
       Z[ii][cc >> 1][cc & 1] = part == 0 ? (c >= r ? v[cc] : 0.0f) : (c == r ? 1.0f : 0.0f);
     }
   }
-  // Step j = 8 jb + jj: the owners of row j publish it UNSCALED (no arithmetic before the barrier); every thread
-  // derives 1/sqrt(pivot) itself and applies  row_r -= (a_jr / d) * (row_j / d)  to the rows below (rows at or
-  // above j get a zero multiplier instead of a mask), the owners scale their own row.  One barrier per step; the
-  // row buffer alternates so a step's readers never meet the next step's writers.
 #pragma unroll 1
   for (int jb = 0; jb < 16; ++jb) {
+    // columns left of the group are finished (A part) / still zero right of it (Y part)
     const bool active = ty >= jb && (part == 0 ? tx >= jb : tx <= jb);
+    if (part == 0 && ty == jb && tx == jb) {
+      float R[8][8], W[8][8];
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      const int buf = jj & 1;
-      if (ty == jb) {
-        float4* dst = reinterpret_cast<float4*>(&rowbuf[buf][part][8 * tx]);
-        dst[0] = make_float4(Z[jj][0][0], Z[jj][0][1], Z[jj][1][0], Z[jj][1][1]);
-        dst[1] = make_float4(Z[jj][2][0], Z[jj][2][1], Z[jj][3][0], Z[jj][3][1]);
+      for (int k = 0; k < 8; ++k) {
+        float s = Z[k][k >> 1][k & 1];
+#pragma unroll
+        for (int i = 0; i < k; ++i) s = __builtin_fmaf(-R[i][k], R[i][k], s);
+        if (!(s > 0.0f)) atomicMin(info, index_base + 8 * jb + k + 1);
+        float inv = __builtin_amdgcn_rsqf(s);
+        inv = inv * (1.5f - 0.5f * s * inv * inv);  // one Newton step: full float32 accuracy
+        R[k][k] = s * inv;
+#pragma unroll
+        for (int c = k + 1; c < 8; ++c) {
+          float t = Z[k][c >> 1][c & 1];
+#pragma unroll
+          for (int i = 0; i < k; ++i) t = __builtin_fmaf(-R[i][k], R[i][c], t);
+          R[k][c] = t * inv;
+        }
+        // row k of L^-1: W[k][k] = 1 / L[k][k], W[k][i] = -W[k][k] * sum_{m = i .. k-1} L[k][m] W[m][i], L[k][m] = R[m][k]
+        W[k][k] = inv;
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+          float t = 0.0f;
+#pragma unroll
+          for (int m = i; m < k; ++m) t = __builtin_fmaf(R[m][k], W[m][i], t);
+          W[k][i] = -inv * t;
+        }
       }
-      __syncthreads();
-      if (active) {
-        const float pivot = rowbuf[buf][0][8 * jb + jj];
-        if (!(pivot > 0.0f) && tid == 255) atomicMin(info, index_base + 8 * jb + jj + 1);
-        float inv = __builtin_amdgcn_rsqf(pivot);
-        inv = inv * (1.5f - 0.5f * pivot * inv * inv);  // one Newton step: full float32 accuracy
-        const f32x2 inv2 = {inv, inv};
-        const float4 m0 = *reinterpret_cast<const float4*>(&rowbuf[buf][0][8 * ty]);
-        const float4 m1 = *reinterpret_cast<const float4*>(&rowbuf[buf][0][8 * ty + 4]);
-        const float4 c0 = *reinterpret_cast<const float4*>(&rowbuf[buf][part][8 * tx]);
-        const float4 c1 = *reinterpret_cast<const float4*>(&rowbuf[buf][part][8 * tx + 4]);
-        const bool below = ty > jb;
-        const float ninv = -inv;
-        const float mr[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-        float m[8];
 #pragma unroll
-        for (int ii = 0; ii < 8; ++ii) m[ii] = (ii > jj || below) ? mr[ii] * ninv : 0.0f;
-        f32x2 rc[4] = {{c0.x, c0.y}, {c0.z, c0.w}, {c1.x, c1.y}, {c1.z, c1.w}};
+      for (int k = 0; k < 8; ++k)
 #pragma unroll
-        for (int h = 0; h < 4; ++h) rc[h] = rc[h] * inv2;
+        for (int i = 0; i < 8; ++i) wmat[k][i] = i <= k ? W[k][i] : 0.0f;
+    }
+    __syncthreads();
+    if (active && ty == jb) {
+      // final rows of the group: rows <- W x rows, from the last row up (row k only needs rows <= k)
+#pragma unroll
+      for (int k = 7; k >= 0; --k) {
+        f32x2 acc[4];
+        const float wkk = wmat[k][k];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) acc[h] = Z[k][h] * f32x2{wkk, wkk};
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+          const float w = wmat[k][i];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) acc[h] = __builtin_elementwise_fma(f32x2{w, w}, Z[i][h], acc[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) Z[k][h] = acc[h];
+        float4* dst = reinterpret_cast<float4*>(&rows[k][part][8 * tx]);
+        dst[0] = make_float4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+        dst[1] = make_float4(acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+      }
+    }
+    __syncthreads();
+    if (active && ty > jb) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 m0 = *reinterpret_cast<const float4*>(&rows[k][0][8 * ty]);
+        const float4 m1 = *reinterpret_cast<const float4*>(&rows[k][0][8 * ty + 4]);
+        const float4 c0 = *reinterpret_cast<const float4*>(&rows[k][part][8 * tx]);
+        const float4 c1 = *reinterpret_cast<const float4*>(&rows[k][part][8 * tx + 4]);
+        const float m[8] = {-m0.x, -m0.y, -m0.z, -m0.w, -m1.x, -m1.y, -m1.z, -m1.w};
+        const f32x2 rc[4] = {{c0.x, c0.y}, {c0.z, c0.w}, {c1.x, c1.y}, {c1.z, c1.w}};
 #pragma unroll
         for (int ii = 0; ii < 8; ++ii) {
           const f32x2 mm = {m[ii], m[ii]};
 #pragma unroll
           for (int h = 0; h < 4; ++h) Z[ii][h] = __builtin_elementwise_fma(mm, rc[h], Z[ii][h]);
         }
-        if (!below) {
-#pragma unroll
-          for (int h = 0; h < 4; ++h) Z[jj][h] = rc[h];
-        }
       }
     }
+    // no barrier here: the next group's W is written after this group's second barrier and read after the next
+    // group's first; `rows` is rewritten after the next group's first barrier, which every reader above has passed
   }
   if (part == 0) {  // R11 in place (strict lower part zero)
 #pragma unroll
