@@ -11,8 +11,8 @@ rows = [dict(name=n, s=s, e=e, stream=st) for n, s, e, st in
 syrk = [r for r in rows if "syrk_kernel" in r["name"] and r["e"] - r["s"] > 30e6]
 # the last big SYRK that starts a whole step (bench.py ends with a pass of Hessians alone: skip those)
 ends = [r["s"] for r in syrk[1:]] + [rows[-1]["e"] + 1]
-starts = [(r, sum(1 for x in rows if r["s"] <= x["s"] < nxt)) for r, nxt in zip(syrk, ends)]
-t0 = [r for r, n in starts if n > 200][-1]["s"]
+starts = [(r, sum(1 for x in rows if r["s"] <= x["s"] < nxt and "sweep" in x["name"])) for r, nxt in zip(syrk, ends)]
+t0 = [r for r, n in starts if n > 0][-1]["s"]
 nxt = min([r["s"] for r in syrk if r["s"] > t0] + [rows[-1]["e"] + 1])
 step = [r for r in rows if t0 - 5e6 <= r["s"] < nxt - 5e6]
 tend = max(r["e"] for r in step)
