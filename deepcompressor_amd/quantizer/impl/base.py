@@ -329,6 +329,8 @@ class QuantizerImpl:
         v0, v1 = first.tensor_view_shape, last.tensor_view_shape
         if tensor.ndim != 2 or not tensor.is_contiguous() or len(v0) != 4 or len(v1) != 4:
             return None
+        if tensor.data_ptr() % 16:  # the kernel moves 16-byte pieces
+            return None
         rows, row_len = tensor.shape
         if tuple(v0) != (rows, 1, 1, row_len) or v1[0] != rows or v1[1] != 1 or v1[2] * v1[3] != row_len:
             return None
