@@ -189,7 +189,37 @@ def _compute_hessian(inputs: TensorCache, device: torch.device, num_samples: int
         if hessian is None:
             hessian = torch.zeros((x2.shape[1], x2.shape[1]), device=device, dtype=torch.float32)
         hessian_accumulate(hessian, x2.to(device=device, non_blocking=True), alpha)
+    if hessian is not None and num_samples is None:
+        _start_diag_mean(hessian)
     return hessian
+
+
+def _diag_for_damping(hessian: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """(dead channels, diagonal with the dead entries set to 1): gptq.py:199-204."""
+    diag = hessian.diagonal()
+    dead = diag == 0
+    return dead, torch.where(dead, torch.ones_like(diag), diag)
+
+
+def _start_diag_mean(hessian: torch.Tensor) -> None:
+    """The damping is a fraction of the mean of the Hessian's diagonal, a host-side number: start its copy to pinned
+    memory right behind the Hessian's kernels, so that the factorisation that needs it later finds it there instead
+    of draining the stream for it."""
+    mean = _diag_for_damping(hessian)[1].mean().reshape(1)
+    host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+    host.copy_(mean, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    hessian._dcq_diag_mean = (host, done)
+
+
+def _diag_mean(hessian: torch.Tensor, diag: torch.Tensor) -> float:
+    early = getattr(hessian, "_dcq_diag_mean", None)
+    if early is None:
+        return float(diag.mean())
+    host, done = early
+    done.synchronize()
+    return float(host[0])
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
@@ -241,6 +271,25 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, alpha: float 
                              float(alpha), float(beta), stream_of(c.device)), "dcq_gemm_f32")
 
 
+def _enqueue_factor(hessian: torch.Tensor, perm: torch.Tensor | None, diag_add: float):
+    """One attempt of ``dcq_cholesky_inverse_upper`` with the given damping, enqueued: (U, info) -- ``info`` (device
+    int32) is 0 once the kernels have run and every pivot was positive."""
+    n = hessian.shape[0]
+    assert hessian.shape == (n, n) and hessian.dtype == torch.float32 and hessian.is_contiguous()
+    dev = hessian.device
+    u = torch.empty((n, n), device=dev, dtype=torch.float32)
+    info = torch.empty(1, device=dev, dtype=torch.int32)
+    ws = _workspace(dev, lib().dcq_cholesky_workspace_bytes(n))
+    check(lib().dcq_cholesky_inverse_upper(ptr(hessian), n, ptr(perm), float(diag_add), ptr(u), ptr(ws), ws.numel(),
+                                           ptr(info), stream_of(dev)), "dcq_cholesky_inverse_upper")
+    return u, info
+
+
+def _damping(damp: float, diag_mean: float, attempt: int) -> float:
+    """gptq.py:209-233: ``damp * mean(diag)``, a tenth more of it on every failed factorisation."""
+    return damp * diag_mean * (1.0 + 0.1 * attempt)
+
+
 def cholesky_inverse_upper(hessian: torch.Tensor, perm: torch.Tensor | None, diag_mean: float, damp: float,
                            num_tries: int):
     """U (upper) with U^T U = S^-1 for S = P H' P^T + damping, H' = ``hessian`` with dead (zero) diagonal
@@ -253,42 +302,45 @@ def cholesky_inverse_upper(hessian: torch.Tensor, perm: torch.Tensor | None, dia
     triangular inverse instead of a symmetric inverse plus a second factorisation (half the flops, and no
     second loss of accuracy).  Both steps run in ``dcq_cholesky_inverse_upper``.
     """
-    n = hessian.shape[0]
-    assert hessian.shape == (n, n) and hessian.dtype == torch.float32 and hessian.is_contiguous()
-    dev = hessian.device
-    u = torch.empty((n, n), device=dev, dtype=torch.float32)
-    info = torch.empty(1, device=dev, dtype=torch.int32)
-    nbytes = lib().dcq_cholesky_workspace_bytes(n)
-    ws = _workspace(dev, nbytes)
-    tries, done = 0, False
+    tries, done, u = 0, False, None
     while not done and tries < num_tries:
-        diag_add = damp * diag_mean * (1.0 + 0.1 * tries)
+        u, info = _enqueue_factor(hessian, perm, _damping(damp, diag_mean, tries))
         tries += 1
-        check(lib().dcq_cholesky_inverse_upper(ptr(hessian), n, ptr(perm), float(diag_add), ptr(u), ptr(ws), ws.numel(),
-                                               ptr(info), stream_of(dev)), "dcq_cholesky_inverse_upper")
         done = int(info.item()) == 0
     assert done, "Hessian could not be factorised"
     engine.assert_finite(u, "Inverse of Hessian matrix", inf_first=True)
     return u, tries
 
 
-def _inverse_factor_of(hessian: torch.Tensor, config: QuantGptqConfig):
-    """(dead channels, act-order permutation, its inverse, U) of a Hessian (gptq.py:199-233), memoised for the most
-    recent Hessian tensor: weights that share their inputs share all four."""
+def _inverse_factor_of(hessian: torch.Tensor, config: QuantGptqConfig, attempt: int = 0):
+    """(dead channels, act-order permutation, its inverse, U, info) of a Hessian (gptq.py:199-233), memoised for the
+    most recent Hessian tensor: weights that share their inputs share them.  The factorisation is only enqueued here:
+    ``info`` is the device flag of attempt number ``attempt`` while nobody has looked at it yet (the caller queues the
+    work that uses U behind it, reads the flag afterwards and reports through ``_factor_verified``), None once it
+    has been seen to be zero."""
     key = (_version_of(hessian), config.damp_percentage, config.num_inv_tries)
     _factor_cache = _state.factor
     hit = _factor_cache["key"]
     if hit is not None and hit[0] is hessian and hit[1] == key:
-        return _factor_cache["value"]
+        value = _factor_cache["value"]
+        if value[4] is None or value[5] == attempt:  # a verified factor serves every caller, whatever it took
+            return value[:5]
     _factor_cache["key"] = _factor_cache["value"] = None
-    diag = hessian.diagonal()
-    dead = diag == 0
-    diag = torch.where(dead, torch.ones_like(diag), diag)
+    dead, diag = _diag_for_damping(hessian)
     perm = torch.argsort(diag, descending=True)
     inverse_perm = torch.argsort(perm)
-    U, _ = cholesky_inverse_upper(hessian, perm, float(diag.mean()), config.damp_percentage, config.num_inv_tries)
-    _factor_cache["key"], _factor_cache["value"] = (hessian, key), (dead, perm, inverse_perm, U)
-    return _factor_cache["value"]
+    U, info = _enqueue_factor(hessian, perm, _damping(config.damp_percentage, _diag_mean(hessian, diag), attempt))
+    _factor_cache["key"], _factor_cache["value"] = (hessian, key), (dead, perm, inverse_perm, U, info, attempt)
+    return _factor_cache["value"][:5]
+
+
+def _factor_verified(hessian: torch.Tensor) -> None:
+    """The memoised factor's flag has been read as zero: later users need not look again."""
+    _factor_cache = _state.factor
+    hit = _factor_cache["key"]
+    if hit is not None and hit[0] is hessian:
+        dead, perm, inverse_perm, U, _, attempt = _factor_cache["value"]
+        _factor_cache["value"] = (dead, perm, inverse_perm, U, None, attempt)
 
 
 @torch.no_grad()
@@ -314,9 +366,7 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     # ---- Hessian (shared, never modified), dead channels, act-order permutation, damping, inverse factor
     hessian = hessian_of(inputs, dev) if hessian is None else hessian
     assert hessian.shape == (Cn, Cn), "activation channels do not match the weight's input channels"
-    dead, perm, inverse_perm, U = _inverse_factor_of(hessian, gptq_config)
-    W = torch.where(dead, torch.zeros((), device=dev, dtype=W.dtype), W)[:, perm].contiguous()
-    # ---- sweep
+    # ---- sweep set-up
     qr = QuantRange.construct(quant_dtype, has_zero_point=zero_domain is not None, quant_range=quant_range)
     step = engine.make_step(quant_dtype=quant_dtype, zero_domain=zero_domain, tensor_quant_range=qr,
                             quant_range=quant_range, scale_dtype=torch.float32, zero_dtype=torch.float32,
@@ -329,15 +379,31 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
             z_scalar = float(zero)
         else:
             z2 = zero.to(torch.float32).reshape(n_rg, n_cg).contiguous()
-    Q = torch.zeros_like(W)
     # Lazy updates at two levels (same sums as gptq.py:269, regrouped): the errors of LAZY_BLOCKS consecutive
     # sweep blocks are collected side by side; columns inside the group are updated after every block (K = 128),
     # the columns right of the group once per group with one K = 128 * LAZY_BLOCKS product, which reads and
     # writes the far part of W LAZY_BLOCKS times less often.
     group_cols = SWEEP_COLUMNS * LAZY_BLOCKS
     err = torch.empty((R, group_cols), device=dev, dtype=torch.float32)
-    check(lib().dcq_gptq_sweep(C.byref(step), ptr(W), Cn, R, Cn, ptr(U), ptr(s2), ptr(z2), z_scalar, rg_size, cg_size,
-                               n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, stream_of(dev)), "dcq_gptq_sweep")
+    # The factorisation is enqueued, not waited for: the sweep goes into the stream right behind it, and only then is
+    # the factorisation's flag read.  A failed attempt (a non-positive pivot: rare, U is garbage then and so is this
+    # sweep's output) is repeated with more damping, as the reference does (gptq.py:209-233).
+    attempt = 0
+    while True:
+        dead, perm, inverse_perm, U, info = _inverse_factor_of(hessian, gptq_config, attempt)
+        Wp = torch.where(dead, torch.zeros((), device=dev, dtype=W.dtype), W)[:, perm].contiguous()
+        Q = torch.zeros_like(Wp)
+        check(lib().dcq_gptq_sweep(C.byref(step), ptr(Wp), Cn, R, Cn, ptr(U), ptr(s2), ptr(z2), z_scalar, rg_size,
+                                   cg_size, n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, stream_of(dev)),
+              "dcq_gptq_sweep")
+        if info is None:
+            break
+        if int(info.item()) == 0:
+            _factor_verified(hessian)
+            engine.assert_finite(U, "Inverse of Hessian matrix", inf_first=True)
+            break
+        attempt += 1
+        assert attempt < gptq_config.num_inv_tries, "Hessian could not be factorised"
     Q = Q[:, inverse_perm]
     engine.assert_finite(Q, "GPTQ Quantized tensor")
     return Q.reshape(n_rg, rg_size, n_cg, cg_size).contiguous()
