@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256) void progressive_int_kernel(const ProgressiveP
   const int tid = threadIdx.x;
   const raw_t* xin = static_cast<const raw_t*>(p.x);
   raw_t* dq_out = static_cast<raw_t*>(p.dequant);
+  const Divisor d_span = make_divisor(p.q_span, 0.0f);
   int parity = 0;
   for (int64_t row = blockIdx.x; row < pp.rows; row += gridDim.x, parity ^= 1) {
     const int64_t base = row * pp.row_pieces;
@@ -519,19 +520,35 @@ __global__ __launch_bounds__(256) void progressive_int_kernel(const ProgressiveP
     if ((tid & 63) == 0) part[parity][tid >> 6] = mx;
     __syncthreads();  // one barrier per row: the next row writes the other half of `part`
     float top = fmaxf(fmaxf(part[parity][0], part[parity][1]), fmaxf(part[parity][2], part[parity][3]));
+    const float row_abs = top;  // largest magnitude of the row as stored
     if (pp.first_has_ratio) top = top * pp.first_ratio;
     if (pp.first_has_bound_max) top = fminf(top, pp.first_bound_max);
     float outer = apply_rounding(pp.first_scale, fabsf(top / pp.first_q_span), nullptr);
     if (outer == 0.0f) outer = 1.0f;
+    // the same value in every lane (it came through LDS): tell the compiler, so that what depends on it alone is
+    // scalar work and scalar branches
+    outer = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(outer)));
     if (tid == 0) pp.first_scale_out[row] = outer;
     const Divisor d_outer = make_divisor(outer, 0.0f);
+    // the hoisted-reciprocal division's guard (see make_divisor) for the whole row at once
+    const bool row_fast = __builtin_amdgcn_readfirstlane(static_cast<int>(d_outer.fast && row_abs <= 0x1p60f)) != 0;
 #pragma unroll
     for (int c = 0; c < PIECES; ++c) {
       const int j = c * 256 + tid;
       if (j >= pp.row_pieces) continue;  // whole teams leave together: a group never straddles the row's end
       float v[VEC], d[VEC], qv[VEC];
       E::unpack(keep[c], v);
-      develop<VEC>(v, outer, d_outer, p);
+      if (row_fast) {
+#pragma unroll
+        for (int i = 0; i < VEC; i += 2) {
+          const f32x2 t = div_fast2(f32x2{v[i], v[i + 1]}, d_outer);
+          v[i] = clamp_f(t.x, p.outer_lo, p.outer_hi);
+          v[i + 1] = clamp_f(t.y, p.outer_lo, p.outer_hi);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = clamp_f(v[i] / outer, p.outer_lo, p.outer_hi);
+      }
       float lmx = ZD == DCQ_ZERO_NONE ? 0.0f : -INFINITY, lmn = INFINITY;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -556,7 +573,14 @@ __global__ __launch_bounds__(256) void progressive_int_kernel(const ProgressiveP
       if (p.has_bound_max) vmax = fminf(vmax, p.bound_max);
       if (ZD != DCQ_ZERO_NONE && p.has_bound_min) vmin = fmaxf(vmin, p.bound_min);
       const float span = ZD != DCQ_ZERO_NONE ? vmax - vmin : vmax;
-      float sc = round_scale<SK>(fabsf(span / p.q_span), p.s_lo, p.s_hi);
+      // span / q_span: the divisor is the same for every group, the guard is voted on by the wave
+      float ratio_to_span;
+      if (__builtin_amdgcn_ballot_w64(!(d_span.fast && fabsf(span) <= 0x1p60f)) == 0) {
+        ratio_to_span = div_fast(span, d_span);
+      } else {
+        ratio_to_span = span / p.q_span;
+      }
+      float sc = round_scale<SK>(fabsf(ratio_to_span), p.s_lo, p.s_hi);
       if (sc == 0.0f) sc = 1.0f;
       float ze = 0.0f;
       if (ZD == DCQ_ZERO_PRE_SCALE) ze = fminf(fmaxf(rintf(p.q_min - vmin / sc), p.z_lo), p.z_hi);
@@ -567,7 +591,7 @@ __global__ __launch_bounds__(256) void progressive_int_kernel(const ProgressiveP
         if (p.scale_out) p.scale_out[g] = sc;
         if (p.zero_out) p.zero_out[g] = ze;
       }
-      if (dv.fast) {
+      if (__builtin_amdgcn_ballot_w64(!dv.fast) == 0) {
 #pragma unroll
         for (int i = 0; i < VEC; i += 2) {
           f32x2 a = {v[i], v[i + 1]};
