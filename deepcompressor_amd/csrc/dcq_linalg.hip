@@ -68,15 +68,19 @@ __device__ __forceinline__ float4 load_piece(const float* row, int col, int limi
 
 // One T x T tile of C by 4 waves (2 x 2 quadrants of T/2 x T/2, each T/64 x T/64 matrix-instruction tiles).
 // T = 128 for throughput; T = 64 spreads small problems over 4x as many compute units (latency-bound regime).
+// `tid` (0..255) is the thread's index in the group of 256 that computes this tile; `extra_barriers` are executed
+// after the tile's own 1 + nk workgroup barriers (a workgroup running two tiles side by side, one per half, keeps
+// both halves on the same barrier count).
 template <bool A_KMAJOR, bool FAST, int T>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m0, int n0, int k_begin, int nk) {
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m0, int n0, int k_begin, int nk,
+                                          int tid, int extra_barriers = 0) {
   constexpr int kGK = GemmStep<T>::value;
   constexpr int LD = T + 4;              // LDS row pitch: the two half-waves of a fragment read hit different banks
   constexpr int IMG = kGK * LD;          // one operand image [k][m or n]
   constexpr int PIECES = kGK * T / 4 / kGemmThreads;  // 16-byte pieces per thread, operand and k-step
   constexpr int KP = kGK / 4;            // pieces per row of a row-major A tile
   constexpr int F = T / 64;              // 32 x 32 tiles per wave and dimension
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   float4 ra[PIECES], rb[PIECES];
   // staging maps.  k-major operand: piece = (k row, 4 consecutive m/n); row-major A: piece = (m row, 4 consecutive k)
@@ -170,6 +174,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m
           *c = p.beta == 0.0f ? v : p.beta * *c + v;
         }
       }
+  for (int i = 0; i < extra_barriers; ++i) __syncthreads();
 }
 
 template <bool A_KMAJOR, int T>
@@ -188,9 +193,9 @@ __global__ __launch_bounds__(kGemmThreads, 4) void gemm_f32_kernel(const GemmPar
   // whole, aligned 16-byte pieces everywhere in this tile?  (uniform over the workgroup)
   const bool fast = p.vec_a && p.vec_b && n0 + T <= p.N && (!A_KMAJOR || m0 + T <= p.M);
   if (fast) {
-    gemm_tile<A_KMAJOR, true, T>(p, lds, m0, n0, k_begin, nk);
+    gemm_tile<A_KMAJOR, true, T>(p, lds, m0, n0, k_begin, nk, threadIdx.x);
   } else {
-    gemm_tile<A_KMAJOR, false, T>(p, lds, m0, n0, k_begin, nk);
+    gemm_tile<A_KMAJOR, false, T>(p, lds, m0, n0, k_begin, nk, threadIdx.x);
   }
 }
 
@@ -246,10 +251,15 @@ static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s) {
 constexpr int kPanelThreads = 512;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(kPanelThreads) void panel_factor_kernel(float* a, int64_t lda, float* x, int64_t ldx,
-                                                                      int32_t* info, int32_t index_base) {
-  __shared__ __align__(16) float rows[8][2][kNb];  // the group's final rows: [row][A part | Y part][column]
-  __shared__ __align__(16) float wmat[8][8];       // W = L^-1 of the group's diagonal block
+struct PanelLds {
+  float rows[8][2][kNb];  // the group's final rows: [row][A part | Y part][column]
+  float wmat[8][8];       // W = L^-1 of the group's diagonal block
+};
+
+__device__ __forceinline__ void panel_factor(float* a, int64_t lda, float* x, int64_t ldx, int32_t* info,
+                                             int32_t index_base, PanelLds& lds) {
+  float (&rows)[8][2][kNb] = lds.rows;
+  float (&wmat)[8][8] = lds.wmat;
   const int tid = threadIdx.x, tx = tid & 15, ty = (tid >> 4) & 15;
   const int part = tid >> 8;  // waves 0-3 hold the A part, waves 4-7 the Y part
   f32x2 Z[8][4];
@@ -368,6 +378,110 @@ __global__ __launch_bounds__(kPanelThreads) void panel_factor_kernel(float* a, i
   }
 }
 
+__global__ __launch_bounds__(kPanelThreads) void panel_factor_kernel(float* a, int64_t lda, float* x, int64_t ldx,
+                                                                      int32_t* info, int32_t index_base) {
+  __shared__ __align__(16) PanelLds lds;
+  panel_factor(a, lda, x, ldx, info, index_base, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two adjacent diagonal blocks in ONE launch: the recursion's lowest internal node (leaf, R12, trailing update,
+// leaf, X12) run by one workgroup.  Launched separately, its six kernels are a few microseconds of work each and
+// spend most of their time waiting to be dispatched next to other streams' kernels; here the workgroup stays
+// resident.  The four 128^3 products run as 64 x 64 tiles, two at a time (one per half of the workgroup); the
+// halves are kept on the same barrier count (gemm_tile's extra_barriers).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPairTile = 64;
+constexpr int kPairGemmFloats = 2 * 2 * GemmStep<kPairTile>::value * (kPairTile + 4);  // one half's double buffer
+
+constexpr size_t kPairPanelBytes = (sizeof(PanelLds) + 255) / 256 * 256;
+constexpr size_t kPairLdsBytes = kPairPanelBytes + 2 * kPairGemmFloats * sizeof(float);
+
+template <bool A_KMAJOR>
+__device__ __forceinline__ void pair_product(GemmParams g, float* lds) {
+  constexpr int T = kPairTile, kGK = GemmStep<T>::value;
+  g.tiles_m = (g.M + T - 1) / T;
+  g.tiles_n = (g.N + T - 1) / T;
+  const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  float* my_lds = lds + half * kPairGemmFloats;
+  // the tiles in a fixed order (skipping those below the diagonal of an upper-only product), two per round
+  int list[4], count = 0;
+  for (int t = 0; t < g.tiles_m * g.tiles_n; ++t) {
+    const int tm = t % g.tiles_m, tn = t / g.tiles_m;
+    if (!(g.upper_only && tn < tm)) list[count++] = t;
+  }
+  auto steps_of = [&](int t, int& k_begin) {
+    const int m0 = (t % g.tiles_m) * T, n0 = (t / g.tiles_m) * T;
+    int k_end = g.K;
+    k_begin = 0;
+    if (g.k_above_m) k_begin = max(k_begin, m0 / kGK * kGK);
+    if (g.k_below_m) k_end = min(k_end, m0 + T);
+    if (g.k_below_n) k_end = min(k_end, n0 + T);
+    return k_end > k_begin ? (k_end - k_begin) / kGK : 0;
+  };
+  for (int r = 0; r < count; r += 2) {
+    int kb0, kb1 = 0;
+    const int nk0 = steps_of(list[r], kb0);
+    const int nk1 = r + 1 < count ? steps_of(list[r + 1], kb1) : -1;  // -1: the second half has no tile this round
+    const int most = max(nk0, nk1);
+    const int mine = half == 0 ? list[r] : (r + 1 < count ? list[r + 1] : -1);
+    if (mine >= 0) {
+      const int m0 = (mine % g.tiles_m) * T, n0 = (mine / g.tiles_m) * T;
+      const int nk = half == 0 ? nk0 : nk1, kb = half == 0 ? kb0 : kb1;
+      gemm_tile<A_KMAJOR, true, T>(g, my_lds, m0, n0, kb, nk, tid, most - nk);
+    } else {
+      for (int i = 0; i < 1 + most; ++i) __syncthreads();
+    }
+  }
+  __syncthreads();  // the product is in memory for every thread of the workgroup
+}
+
+__global__ __launch_bounds__(kPanelThreads) void pair_factor_kernel(float* A, float* X, float* Tm, int64_t np,
+                                                                     int32_t first_block, int32_t* info) {
+  extern __shared__ __align__(16) unsigned char pair_smem[];  // kPairLdsBytes: [PanelLds | two halves' tile buffers]
+  PanelLds& panel_lds = *reinterpret_cast<PanelLds*>(pair_smem);
+  float* gemm_lds = reinterpret_cast<float*>(pair_smem + kPairPanelBytes);
+  const int64_t o1 = static_cast<int64_t>(first_block) * kNb, o2 = o1 + kNb;
+  float* a11 = A + o1 * np + o1;
+  float* a12 = A + o1 * np + o2;
+  float* a22 = A + o2 * np + o2;
+  float* x11 = X + o1 * np + o1;
+  float* x12 = X + o1 * np + o2;
+  float* x22 = X + o2 * np + o2;
+  panel_factor(a11, np, x11, np, info, static_cast<int32_t>(o1), panel_lds);
+  __syncthreads();
+  GemmParams g{};
+  g.M = g.N = g.K = kNb;
+  g.vec_a = g.vec_b = 1;
+  {  // R12 = X11^T A12 -> Tm, then copied over A12
+    g.A = x11, g.lda = np, g.B = a12, g.ldb = np, g.C = Tm, g.ldc = kNb;
+    g.alpha = 1.0f, g.beta = 0.0f, g.upper_only = 0, g.k_above_m = 0, g.k_below_m = 1, g.k_below_n = 0;
+    pair_product<true>(g, gemm_lds);
+    for (int e = threadIdx.x; e < kNb * kNb / 4; e += kPanelThreads) {
+      const int r = e / (kNb / 4), c4 = (e % (kNb / 4)) * 4;
+      *reinterpret_cast<float4*>(a12 + r * np + c4) = *reinterpret_cast<const float4*>(Tm + r * kNb + c4);
+    }
+    __syncthreads();
+  }
+  {  // A22 -= R12^T R12 (upper triangle)
+    g.A = a12, g.lda = np, g.B = a12, g.ldb = np, g.C = a22, g.ldc = np;
+    g.alpha = -1.0f, g.beta = 1.0f, g.upper_only = 1, g.k_above_m = 0, g.k_below_m = 0, g.k_below_n = 0;
+    pair_product<true>(g, gemm_lds);
+  }
+  panel_factor(a22, np, x22, np, info, static_cast<int32_t>(o2), panel_lds);
+  __syncthreads();
+  {  // Tm = R12 X22 (X22 upper: k <= n)
+    g.A = a12, g.lda = np, g.B = x22, g.ldb = np, g.C = Tm, g.ldc = kNb;
+    g.alpha = 1.0f, g.beta = 0.0f, g.upper_only = 0, g.k_above_m = 0, g.k_below_m = 0, g.k_below_n = 1;
+    pair_product<false>(g, gemm_lds);
+  }
+  {  // X12 = -X11 Tm (X11 upper: k >= m)
+    g.A = x11, g.lda = np, g.B = Tm, g.ldb = kNb, g.C = x12, g.ldc = np;
+    g.alpha = -1.0f, g.beta = 0.0f, g.upper_only = 0, g.k_above_m = 1, g.k_below_m = 0, g.k_below_n = 0;
+    pair_product<false>(g, gemm_lds);
+  }
+}
+
 // dst[i][j] = S[n-1-i][n-1-j] for i, j < n and the identity on the padding up to np, where
 // S = P H' P^T + diag_add * I, H' = H with zero diagonal entries replaced by 1, P the row gather `perm` (or identity)
 __global__ void flip_pad_kernel(const float* src, int64_t n, const int64_t* perm, float diag_add, float* dst,
@@ -444,6 +558,22 @@ static int factor_invert(float* A, float* X, float* T, int64_t np, int lo, int h
     const int64_t off = (static_cast<int64_t>(lo) * kNb) * (np + 1);
     hipLaunchKernelGGL(panel_factor_kernel, dim3(1), dim3(kPanelThreads), 0, s, A + off, np, X + off, np, info, lo * kNb);
     DCQ_LAUNCH_CHECK("panel_factor_kernel launch");
+    return DCQ_OK;
+  }
+  if (hi - lo == 2) {
+    static bool configured[64] = {};
+    int dev = 0;
+    int rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
+    if (rc != DCQ_OK) return rc;
+    if (dev < 0 || dev >= 64 || !configured[dev]) {
+      rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_factor_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPairLdsBytes)),
+                     "hipFuncSetAttribute(pair LDS)");
+      if (rc != DCQ_OK) return rc;
+      if (dev >= 0 && dev < 64) configured[dev] = true;
+    }
+    hipLaunchKernelGGL(pair_factor_kernel, dim3(1), dim3(kPanelThreads), kPairLdsBytes, s, A, X, T, np, lo, info);
+    DCQ_LAUNCH_CHECK("pair_factor_kernel launch");
     return DCQ_OK;
   }
   const int mid = lo + (hi - lo + 1) / 2;

@@ -1,4 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
+timeout -k 10 120 python -u -m pytest tests/test_gpu_gptq.py -x -q --timeout 60 --timeout-method thread -k "inverse" 2>&1 | tail -5
+timeout -k 10 120 python3 tools/quick_linalg.py inv 256 1024 4096 14336
 timeout -k 10 600 python -u -m pytest tests/test_gpu_gptq.py tests/test_zz_no_alloc.py tests/test_gpu_headline_tokens.py tests/test_gpu_full_size.py tests/test_gpu_llm_stage.py -x -q --timeout 300 --timeout-method thread 2>&1 | tail -5
-timeout -k 10 200 python3 tools/quick_linalg.py inv 128 1024 4096 14336
