@@ -87,8 +87,6 @@ class QuantizerImpl:
         if develop_dtype != torch.float32:
             raise NotImplementedError("the HIP kernels compute in float32 (develop_dtype=torch.float32)")
         n_steps = self.info.num_steps
-        if n_steps > 2:
-            raise NotImplementedError("more than two progressive steps are not implemented")
         # ---- normalise the per-step arguments
         if scale is None:
             scale = (None,) * n_steps
@@ -103,6 +101,9 @@ class QuantizerImpl:
             "dynamic_range must have one entry per step")
         if isinstance(kernel, BaseQuantKernelConfig):
             kernel = kernel.build()
+        if n_steps > 2:
+            return self._quantize_chain(tensor, kernel, scale, zero, dynamic_range, round_delta, return_with_dequant,
+                                        return_with_quant, kwargs)
         native_rtn = kernel is None or type(kernel) is QuantRtnKernel
         last = self.info.steps[-1]
         dr_last = dynamic_range[-1]
@@ -183,6 +184,52 @@ class QuantizerImpl:
         return QuantTensor(dequantized=restore(dq) if want_dequant else None, quantized=quantized,
                            scale=QuantScale().append(scale) if want_quant else None, zero=zero,
                            view_shape=view if want_quant else None)
+
+    # ---- more than two progressive steps ------------------------------------------------------
+    def _quantize_chain(self, tensor, kernel, scale, zero, dynamic_range, round_delta, want_dequant, want_quant,
+                        kwargs) -> QuantTensor:
+        """Three or more progressive steps (the reference's loop takes any number, impl/base.py:211-279; none of its
+        example configurations has more than two).  Every step but the last two is applied on its own -- the step's
+        scale from the developed tensor, then develop <- clamp(develop / scale) in float32 --, the last two run as a
+        two-step quantizer on the developed tensor, and the de-quantization walks back through the earlier steps,
+        clamping to each step's dtype on the way (base.py:270-278)."""
+        info, shape, dtype = self.info, tensor.shape, tensor.dtype
+        n_steps = info.num_steps
+        develop = tensor.to(torch.float32)
+        earlier: list[QuantScale] = []
+        for i in range(n_steps - 2):
+            step_info = info.steps[i]
+            step_scale, _ = step_info.scale.quantize(scale=scale[i], zero=None, tensor=develop,
+                                                     dynamic_range=dynamic_range[i], outer=None, outer_range=None)
+            earlier.append(step_scale)
+            bounds = step_info.tensor_quant_range
+            develop = develop.view(step_info.tensor_view_shape).div(step_scale.data).view(shape)
+            develop = develop.clamp_(min=bounds.min, max=bounds.max)
+        self.info = QuantInfo(steps=info.steps[-2:], needs_dequant_saturation=info.needs_dequant_saturation)
+        try:
+            inner = self._quantize_general(develop, kernel, tuple(scale[-2:]), zero, tuple(dynamic_range[-2:]),
+                                           round_delta, want_dequant, want_quant, kwargs)
+        finally:
+            self.info = info
+        dequantized = None
+        if want_dequant:
+            d = inner.data
+            for i in range(n_steps - 3, -1, -1):
+                step_info = info.steps[i]
+                d = d.clamp_(min=step_info.quant_dtype.min_value, max=step_info.quant_dtype.max_value)
+                d = d.view(step_info.tensor_view_shape).mul_(earlier[i].data).view(shape)
+            dequantized = d.to(dtype)
+        quantized = quant_scale = None
+        if want_quant:
+            # with both outputs the reference's qdata aliases the float32 buffer it de-quantizes in place
+            quantized = d if want_dequant else inner.qdata
+            quant_scale = QuantScale()
+            for step_scale in earlier:
+                quant_scale.append(step_scale)
+            for k in range(2):
+                quant_scale.append(inner.scale.get_child(k))
+        return QuantTensor(dequantized=dequantized, quantized=quantized, scale=quant_scale,
+                           zero=inner.zero if want_quant else None, view_shape=inner.view_shape if want_quant else None)
 
     # ---- general path ------------------------------------------------------------------------
     def _quantize_general(self, tensor, kernel, scale, zero, dynamic_range, round_delta, want_dequant, want_quant,

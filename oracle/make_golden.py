@@ -1912,11 +1912,56 @@ def gen_fp_zero(ref) -> None:
                               for k, v in FP_ZERO_CASES.items()}, entries=meta), f, indent=1)
 
 
+# Three progressive steps (no example config of the reference uses them; impl/base.py:211-279 handles any number):
+# per-row fp16 scales onto sint8, groups of 256 with integer scales onto sint6, groups of 64 onto uint4.
+THREE_STEP_CASES = {
+    "three_post": dict(dtype="uint4", zero="PostScale", groups=((1, -1), (1, 256), (1, 64)), sdt=("f16", "sint8", "sint8"),
+                       inter=("sint8", "sint6"), levels=(0, 1), shape=(32, 512)),
+    "three_pre": dict(dtype="uint4", zero="PreScale", groups=((1, -1), (1, 256), (1, 64)), sdt=("f16", "sint8", "sint8"),
+                      inter=("sint8", "sint6"), levels=(0, 1), shape=(16, 512)),
+    "three_sym": dict(dtype="sint4", zero=None, groups=((1, -1), (1, 128), (1, 32)), sdt=("f16", "sint8", "sint8"),
+                      inter=("sint8", "sint6"), levels=(0, 1), shape=(16, 256)),
+}
+
+
+def gen_three_steps(ref) -> None:
+    from deepcompressor.data.range import DynamicRange
+
+    meta, arrays = {}, {}
+    for cname, case in THREE_STEP_CASES.items():
+        for dt in ("bf16", "f16", "f32"):
+            for dyn in (None, (0.9, 1.0, 0.8)):
+                if dyn is not None and dt != "bf16":
+                    continue
+                w = _mk_input(case["shape"], dt, seed=len(cname) * 5 + len(dt))
+                q = _build_quantizer(ref, case)
+                kwargs = {}
+                if dyn is not None:
+                    kwargs["dynamic_range"] = tuple(DynamicRange(ratio=r) for r in dyn)
+                codes = q.quantize(w, return_with_dequant=False, return_with_quant=True, **kwargs)
+                deq = q.quantize(w, return_with_dequant=True, return_with_quant=False, **kwargs)
+                tag = f"{cname}|{dt}" + ("|ratios" if dyn else "")
+                arrays[f"{tag}|x"] = _np(w)
+                arrays[f"{tag}|codes"] = _np(codes.qdata)
+                arrays[f"{tag}|dequant"] = _np(deq.data)
+                arrays[f"{tag}|scale"] = _np(codes.scale.data)
+                sd = codes.scale.state_dict("s")
+                for lvl, leaf in enumerate(sd.values()):
+                    arrays[f"{tag}|leaf{lvl}"] = _np(leaf)
+                arrays[f"{tag}|zero"] = _np(codes.zero)
+                meta[tag] = dict(case=cname, in_dtype=dt, dyn=list(dyn) if dyn else None,
+                                 view_shape=list(codes.view_shape), n_leaves=len(sd))
+    np.savez_compressed(os.path.join(OUT, "three_steps.npz"), **arrays)
+    with open(os.path.join(OUT, "three_steps.json"), "w") as f:
+        json.dump(dict(cases={k: {kk: (list(vv) if isinstance(vv, tuple) else vv) for kk, vv in v.items()}
+                              for k, v in THREE_STEP_CASES.items()}, entries=meta), f, indent=1)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "llm_layer_stages", "patch_linear", "ste", "smooth_tensor", "branch"]
+    which = sys.argv[1:] or ["fake_quant", "range_search", "range_wide", "range_products", "tables", "gptq", "rotate", "smooth", "smooth_attn", "smooth_lowrank", "lowrank", "range_acts", "reorder", "llm_stage", "round_delta", "exp_scale", "qserve", "fp_zero", "nunchaku", "smooth_products", "range_acts_products", "llm_layer_stages", "patch_linear", "ste", "smooth_tensor", "branch", "three_steps"]
     for name in which:
         globals()[f"gen_{name}"](ref)
         print("generated", name)
