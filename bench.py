@@ -189,15 +189,19 @@ def stage_rooflines(device, weights, objs) -> list:
         dtype=QuantDataType.from_str("uint4"), zero_point=ZeroPointDomain.PostScale, group_shapes=((1, -1), (1, 128)),
         scale_dtypes=(torch.float16, QuantDataType.from_str("sint8")),
         intermediate_dtypes=(QuantDataType.from_str("sint8"),), intermediate_levels=(0,)), key="qoq")
-    for label, quantizer, nbytes in (
+    for label, quantizer, nbytes, kernels in (
             ("tensor_absmax_kernel + fused_table_kernel (NVFP4 g16: two reads, one write, two float32 scales per group)",
-             nvfp4, n_big * 6 + (n_big // 16) * 8),
+             nvfp4, n_big * 6 + (n_big // 16) * 8, ("tensor_absmax_kernel", "fused_table_kernel")),
             ("progressive_int_kernel (QoQ W4 g128: per-row fp16 scale and uint4 groups with integer scales, one pass)",
-             qoq, n_big * 4 + (n_big // 128) * 8 + big.shape[0] * 4)):
+             qoq, n_big * 4 + (n_big // 128) * 8 + big.shape[0] * 4, ("progressive_int_kernel",))):
         t = timed(lambda: quantizer.quantize(big), 10)
+        counted = [_pmc(k).get("hbm_bytes") for k in kernels]
         out.append({"kernel": label, "bound": "hbm", "shape": list(big.shape), "achieved": nbytes / t / 1e9,
                     "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 8e12, "algorithmic_bytes": nbytes,
-                    "traffic": None, "avg_launch_ms": t * 1e3,
+                    "traffic": sum(counted) if all(c is not None for c in counted) else None,
+                    "avg_launch_ms": t * 1e3,
+                    "valu_insts_per_launch": sum(_pmc(k).get("avg_per_launch", {}).get("SQ_INSTS_VALU") or 0
+                                                 for k in kernels) or None,
                     "note": "duration of the whole quantize() call (all its launches)"})
     del big
     w = weights["gate_proj"]
