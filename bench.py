@@ -413,7 +413,7 @@ def main() -> None:
         from deepcompressor_amd.quantizer.kernel import gptq as gptq_mod
 
         seen = set()
-        for _, _, c, key in LLAMA3_8B_LAYER:
+        for _, _, c, key in sorted(LLAMA3_8B_LAYER, key=lambda row: -row[2]):  # largest first, as in the step
             if key in seen:
                 continue
             seen.add(key)

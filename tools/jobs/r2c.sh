@@ -2,7 +2,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2b
+O=gpurun_out/r2c
 mkdir -p $O
 if [ -z "$SKIP_TESTS" ]; then
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $O/tests.log 2>&1 || { tail -20 $O/tests.log; exit 1; }
@@ -22,14 +22,14 @@ timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/syrk_write -o w -- python3 
 python3 tools/kernel_pmc.py $O/syrk_pmc.json "syrk_kernel" $(find $O/syrk_fetch $O/syrk_write -name "*.db") > /dev/null
 python3 - <<'PY'
 import json
-d = json.load(open("gpurun_out/r2b/syrk_pmc.json"))
+d = json.load(open("gpurun_out/r2c/syrk_pmc.json"))
 k = d["kernels"]["syrk_kernel"]
 out = {"kernel": "syrk_kernel (bench.py --steps 1 --warmup 0: the step's 4 launches and the 4 launches of the pass with "
                  "nothing else on the chip; C = 14336 once and C = 4096 three times in each, T = 262144)",
        "method": d["method"], "launches_per_pass": k["launches_per_pass"], "avg_per_launch": k["avg_per_launch"],
        "avg_hbm_bytes_per_launch": k["hbm_bytes"]}
-json.dump(out, open("gpurun_out/r2b/syrk_traffic.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r2c/syrk_traffic.json", "w"), indent=1)
 print(json.dumps(out)[:400])
 PY
 find $O -name "*.db" -delete
-echo r2b done
+echo r2c done
