@@ -422,7 +422,7 @@ __device__ __forceinline__ void pair_product(GemmParams g, float* lds) {
   for (int r = 0; r < count; r += 2) {
     int kb0, kb1 = 0;
     const int nk0 = steps_of(list[r], kb0);
-    const int nk1 = r + 1 < count ? steps_of(list[r + 1], kb1) : -1;  // -1: the second half has no tile this round
+    const int nk1 = r + 1 < count ? steps_of(list[r + 1], kb1) : -1;  // -1: the second half has no tile in this pass
     const int most = max(nk0, nk1);
     const int mine = half == 0 ? list[r] : (r + 1 < count ? list[r + 1] : -1);
     if (mine >= 0) {

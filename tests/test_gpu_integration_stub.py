@@ -1,4 +1,4 @@
-"""The reference-side binding printed in INTEGRATION.md, executed as printed.
+"""The reference-side binding printed in the repository's integration notes, executed as printed.
 
 The block that replaces ``deepcompressor/csrc/load.py`` (a ctypes ``_C`` with ``round_to_nearest_in_codebook_cuda``) is
 cut out of the document, run with the library's real path, and called the way ``Codebook.round`` calls it
