@@ -26,7 +26,7 @@ namespace dcq {
 constexpr int kTrTile = 64;
 
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* __restrict__ x, int64_t T, int64_t C,
-                                                            uint16_t* __restrict__ xt, int64_t ldt) {
+                                                            uint16_t* __restrict__ xt, int64_t ktiles) {
   __shared__ uint16_t tile[kTrTile][kTrTile + 2];
   const int64_t t0 = static_cast<int64_t>(blockIdx.x) * kTrTile;
   const int64_t c0 = static_cast<int64_t>(blockIdx.y) * kTrTile;
@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* __re
     uint16_t* pr = reinterpret_cast<uint16_t*>(&raw);
 #pragma unroll
     for (int i = 0; i < 8; ++i) pr[i] = tile[lc + i][c];
-    *reinterpret_cast<uint4*>(xt + (c0 + c) * ldt + t0 + lc) = raw;
+    // blocked layout [panel of 256 channels][k-tile of 64 tokens][channel in panel][token in k-tile]: the 32 KiB
+    // a SYRK workgroup stages per operand and k-tile are one contiguous block
+    const int64_t ch = c0 + c;
+    *reinterpret_cast<uint4*>(xt + (((ch >> 8) * ktiles + blockIdx.x) * 256 + (ch & 255)) * 64 + lc) = raw;
   }
 }
 
@@ -76,7 +79,10 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint16_t* __re
 // of a tile is row-major [256 rows][8 chunks of 16 B]; one wave-instruction fills 8 consecutive rows, its 8
 // lanes per row fetch one full 128-byte line.  To keep the 16-byte fragment reads conflict-free the chunk
 // position is XOR-swizzled with bits 1..3 of the row; direct-to-LDS writes are lane-linear, so the swizzle is
-// applied to the *global source* chunk and again on the read.
+// applied to the *global source* chunk and again on the read.  In memory the transposed activations are blocked
+// the same way, [panel of 256 channels][k-tile][256 rows][64 tokens]: what a workgroup stages per operand and
+// k-tile is one contiguous 32 KiB block, every wave-instruction of the staging reads 1 KiB of consecutive bytes
+// (rows of a plain [channel][token] matrix are half a megabyte apart: 512 separate 128-byte lines per k-tile).
 //
 // Workgroups are renumbered so that the workgroups resident on one XCD (blockIdx = xcd mod 8) walk one
 // 8 x 8 patch of output tiles: every row/column panel streamed from memory is then shared by several workgroups
@@ -131,8 +137,8 @@ __device__ __forceinline__ void load_to_lds_16(const void* gsrc, void* lds_wave_
 __device__ __forceinline__ void wait_direct_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0) only
 
 struct SyrkParams {
-  const uint16_t* xt;  // [Cp][ldt], Tp columns used
-  int64_t Tp, ldt;
+  const uint16_t* xt;  // [Cp / 256][ktiles][256][64]: blocked transposed copy of X (transpose_pad_kernel)
+  int64_t Tp, ktiles;
   int32_t C, Cp;
   int32_t tiles_per_side;  // Cp / 256
   int32_t num_tiles;       // upper triangle incl. diagonal
@@ -208,16 +214,16 @@ __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams 
   for (int it = 0; it < 4; ++it) {
     const int row = wave * 32 + it * 8 + st_row;
     const int chunk = st_pos ^ ((row >> 1) & 7);
-    a_src[it] = p.xt + (static_cast<int64_t>(bi) * kTile + row) * p.ldt + k_begin + chunk * 8;
-    b_src[it] = p.xt + (static_cast<int64_t>(bj) * kTile + row) * p.ldt + k_begin + chunk * 8;
+    a_src[it] = p.xt + ((static_cast<int64_t>(bi) * p.ktiles + k_begin / kBK) * kTile + row) * kBK + chunk * 8;
+    b_src[it] = p.xt + ((static_cast<int64_t>(bj) * p.ktiles + k_begin / kBK) * kTile + row) * kBK + chunk * 8;
   }
 #define DCQ_STAGE(buf, kt)                                                                      \
   do {                                                                                          \
     unsigned char* a_dst = lds + (buf) * 2 * kOperandBytes + wave * 32 * kRowBytes;             \
     unsigned char* b_dst = a_dst + kOperandBytes;                                               \
     _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                          \
-      load_to_lds_16(a_src[it] + static_cast<int64_t>(kt) * kBK, a_dst + it * 8 * kRowBytes);  \
-      if (!diag) load_to_lds_16(b_src[it] + static_cast<int64_t>(kt) * kBK, b_dst + it * 8 * kRowBytes); \
+      load_to_lds_16(a_src[it] + static_cast<int64_t>(kt) * (kTile * kBK), a_dst + it * 8 * kRowBytes);  \
+      if (!diag) load_to_lds_16(b_src[it] + static_cast<int64_t>(kt) * (kTile * kBK), b_dst + it * 8 * kRowBytes); \
     }                                                                                           \
   } while (0)
 
@@ -358,7 +364,7 @@ static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 struct HessianPlan {
-  int64_t Cp, Tp, ldt;
+  int64_t Cp, Tp, ktiles;
   int tiles_side, num_tiles, splits, ktiles_per_split;
   size_t xt_bytes, map_bytes, partial_bytes;
 };
@@ -367,12 +373,10 @@ static HessianPlan plan_hessian(int64_t T, int64_t C) {
   HessianPlan h;
   h.Cp = round_up(C, kTile);
   h.Tp = round_up(T, kBK);
-  // row pitch of the transposed copy: never a power of two.  With a pitch of 2^k bytes the 256 rows of an operand
-  // panel fall into the same L2 sets and evict each other (measured: 8x the algorithmic HBM-side traffic).
-  h.ldt = h.Tp + 64;
+  h.ktiles = h.Tp / kBK;  // k-tiles per panel (blocked layout, see transpose_pad_kernel)
   h.tiles_side = static_cast<int>(h.Cp / kTile);
   h.num_tiles = h.tiles_side * (h.tiles_side + 1) / 2;
-  const int ktiles = static_cast<int>(h.Tp / kBK);
+  const int ktiles = static_cast<int>(h.ktiles);
   // one workgroup per compute unit: pick the K split whose workgroup count fills whole rounds of 256 best,
   // with at least 32 k-tiles per split and at most 1.5 GB of partial slabs
   int splits = 1;
@@ -390,7 +394,7 @@ static HessianPlan plan_hessian(int64_t T, int64_t C) {
   }
   h.splits = splits;
   h.ktiles_per_split = (ktiles + splits - 1) / splits;
-  h.xt_bytes = static_cast<size_t>(round_up(h.Cp * h.ldt * 2, 256));
+  h.xt_bytes = static_cast<size_t>(round_up(h.Cp * h.Tp * 2, 256));
   h.map_bytes = static_cast<size_t>(round_up(static_cast<int64_t>(h.num_tiles) * 8, 256));
   h.partial_bytes = splits > 1 ? static_cast<size_t>(splits) * h.num_tiles * kTile * kTile * 4 : 0;
   return h;
@@ -756,7 +760,7 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
     DCQ_REQUIRE(aligned || (C % 8) != 0, DCQ_ERR_ARGUMENT, "x must be 16-byte aligned");
     dim3 grid(static_cast<unsigned>(h.Tp / kTrTile), static_cast<unsigned>(h.Cp / kTrTile));
-    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, s, static_cast<const uint16_t*>(x), T, C, xt, h.ldt);
+    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, s, static_cast<const uint16_t*>(x), T, C, xt, h.ktiles);
     DCQ_LAUNCH_CHECK("transpose_pad_kernel launch");
   }
   hipLaunchKernelGGL(syrk_tile_map_kernel, dim3((h.num_tiles + 255) / 256), dim3(256), 0, s, tile_map, h.tiles_side,
@@ -766,7 +770,7 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
   p.tile_map = tile_map;
   p.xt = xt;
   p.Tp = h.Tp;
-  p.ldt = h.ldt;
+  p.ktiles = h.ktiles;
   p.C = static_cast<int32_t>(C);
   p.Cp = static_cast<int32_t>(h.Cp);
   p.tiles_per_side = h.tiles_side;
