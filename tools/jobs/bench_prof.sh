@@ -7,4 +7,4 @@ python3 -c "
 import json
 d=json.loads(open('gpurun_out/bp/bench.json').read().strip().splitlines()[-1]); print('ms_per_step', d['ms_per_step'])"
 python3 tools/trace_timeline.py $(find gpurun_out/bp/prof -name "*.db" | head -1)
-python3 tools/prof_db.py $(find gpurun_out/bp/prof -name "*.db" | head -1) 22
+python3 tools/prof_db.py $(find gpurun_out/bp/prof -name "*.db" | head -1) 14; find gpurun_out/bp -name "*.db" -delete
