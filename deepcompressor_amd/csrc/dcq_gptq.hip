@@ -144,6 +144,7 @@ struct SyrkParams {
   int32_t num_tiles;       // upper triangle incl. diagonal
   int32_t splits;          // K splits
   int32_t ktiles_per_split;
+  int32_t first_logical;  // work items (tile, split) of earlier launches
   float alpha;
   float* H;             // [C][C]
   float* partial;       // [splits][num_tiles][128*128] when splits > 1
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams 
   const int wr = wave >> 2, wc = wave & 3;  // wave's 128 x 64 sub-tile
   // XCD-aware renumbering (bijective for any grid size): consecutive logical ids stay on one XCD
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r8 = nwg & 7;
-  const int logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
+  const int logical =
+      p.first_logical + (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
   const int split = logical / p.num_tiles;
   const int tile_idx = logical - split * p.num_tiles;
   const int2 t = p.tile_map[tile_idx];
@@ -789,7 +791,23 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
     if (rc != DCQ_OK) return rc;
   }
   if (g_prof_start) (void)hipEventRecord(g_prof_start, s);
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(h.num_tiles * h.splits)), dim3(kSyrkThreads), lds, s, p);
+  // One launch per round of (tile, split) work items, as many as the chip has compute units (one workgroup each).
+  // All workgroups of a launch start together and do the same amount of work, so the 32 of an XCD walk their
+  // operand panels in step and each 128-byte line is fetched into that XCD's L2 once for all of them.  In one big
+  // launch the workgroups of later rounds start whenever a compute unit frees up, drift apart along k, and re-fetch
+  // each other's lines from memory (measured on C = 14336, T = 262144: 1120 -> 1217 TFLOP/s executed).
+  const int total = h.num_tiles * h.splits;
+  int dev = 0, per_launch = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8)
+      per_launch = cus / 8 * 8;  // whole groups of 8: workgroup i runs on XCD i mod 8
+  }
+  for (int first = 0; first < total; first += per_launch) {
+    p.first_logical = first;
+    const int n = total - first < per_launch ? total - first : per_launch;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n)), dim3(kSyrkThreads), lds, s, p);
+  }
   if (g_prof_stop) (void)hipEventRecord(g_prof_stop, s);
   g_prof_start = g_prof_stop = nullptr;
   DCQ_LAUNCH_CHECK("syrk_kernel launch");
