@@ -8,8 +8,18 @@ import sys
 con = sqlite3.connect(sys.argv[1])
 rows = [dict(name=n, s=s, e=e, stream=st) for n, s, e, st in
         con.execute("select name, start, end, stream_id from kernels order by start")]
-syrk = [r for r in rows if "syrk_kernel" in r["name"] and r["e"] - r["s"] > 30e6]
-# the last big SYRK that starts a whole step (bench.py ends with a pass of Hessians alone: skip those)
+# A Hessian is a run of back-to-back syrk_kernel launches (one per round of workgroups); the big one (C = 14336) is the
+# run that lasts more than 30 ms.  A step starts at its big Hessian.
+runs = []
+for r in rows:
+    if "syrk_kernel" not in r["name"]:
+        continue
+    if runs and r["s"] - runs[-1]["e"] < 0.5e6:
+        runs[-1]["e"] = r["e"]
+    else:
+        runs.append(dict(s=r["s"], e=r["e"]))
+syrk = [g for g in runs if g["e"] - g["s"] > 30e6]
+# the last big Hessian that starts a whole step (bench.py ends with a pass of Hessians alone: skip those)
 ends = [r["s"] for r in syrk[1:]] + [rows[-1]["e"] + 1]
 starts = [(r, sum(1 for x in rows if r["s"] <= x["s"] < nxt and "sweep" in x["name"])) for r, nxt in zip(syrk, ends)]
 t0 = [r for r, n in starts if n > 0][-1]["s"]
