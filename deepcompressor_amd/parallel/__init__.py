@@ -137,6 +137,19 @@ def _all_gather_ragged(parts: list[torch.Tensor], mine: torch.Tensor, rank: int,
         dist.broadcast(parts[r], src=r)
 
 
+_job_streams: dict = {}
+_job_streams_lock = __import__("threading").Lock()
+
+
+def _job_stream(device: torch.device, slot: int, priority: int) -> "torch.cuda.Stream":
+    key = (device.index, slot, priority)
+    with _job_streams_lock:
+        stream = _job_streams.get(key)
+        if stream is None:
+            stream = _job_streams[key] = torch.cuda.Stream(device=device, priority=priority)
+    return stream
+
+
 def run_on_streams(jobs, device: torch.device | str | None = None, priorities: list[int] | None = None,
                    after: list | None = None) -> list:
     """Run independent jobs concurrently on ONE GPU, each on its own HIP stream driven by its own host thread, and
@@ -163,7 +176,9 @@ def run_on_streams(jobs, device: torch.device | str | None = None, priorities: l
         return [job() for job in jobs]
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     caller = torch.cuda.current_stream(dev)
-    streams = [torch.cuda.Stream(device=dev, priority=(priorities[i] if priorities else 0)) for i in range(len(jobs))]
+    # the same stream objects call after call: the caching allocator keeps a pool of freed blocks per stream, so a job
+    # that lands on the stream its predecessor used finds its buffers there instead of allocating device memory anew
+    streams = [_job_stream(dev, i, priorities[i] if priorities else 0) for i in range(len(jobs))]
     results, errors = [None] * len(jobs), [None] * len(jobs)
     grad_mode, inference = torch.is_grad_enabled(), torch.is_inference_mode_enabled()
 
