@@ -283,7 +283,8 @@ int dcq_selftest_division(const float* x, const float* s, float* fast, float* re
 int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C);
 
 /* Measurement hook (no reference counterpart): the calling thread's next dcq_hessian_accumulate records
- * `start` right before and `stop` right after its matrix-core kernel on the call's stream (hipEvent_t
+ * `start` right before and `stop` right after its matrix-core kernel launches (one per round of workgroups) on the
+ * call's stream (hipEvent_t
  * handles, created by the caller with timing enabled), then forgets them.  Pass NULLs to disarm. */
 void dcq_profile_next_hessian(void* start, void* stop);
 
