@@ -498,6 +498,31 @@ __global__ void flip_pad_kernel(const float* src, int64_t n, const int64_t* perm
   dst[i * np + j] = v;
 }
 
+// The same for a permuted source whose rows fit the LDS: one workgroup per destination row stages the source row
+// with coalesced loads and gathers the columns from the LDS, so no global read is scattered.
+constexpr int64_t kFlipRowLdsFloats = 40960;  // 160 KB
+__global__ __launch_bounds__(256) void flip_pad_rows_kernel(const float* src, int64_t n, const int64_t* perm, float diag_add,
+                                                            float* dst, int64_t np) {
+  extern __shared__ float flip_row[];
+  const int64_t i = blockIdx.x;
+  float* out = dst + i * np;
+  if (i >= n) {
+    for (int64_t j = threadIdx.x; j < np; j += 256) out[j] = i == j ? 1.0f : 0.0f;
+    return;
+  }
+  const float* row = src + perm[n - 1 - i] * n;
+  for (int64_t j = threadIdx.x; j < n; j += 256) flip_row[j] = row[j];
+  __syncthreads();
+  for (int64_t j = threadIdx.x; j < np; j += 256) {
+    float v = 0.0f;
+    if (j < n) {
+      v = flip_row[perm[n - 1 - j]];
+      if (i == j) v = (v == 0.0f ? 1.0f : v) + diag_add;
+    }
+    out[j] = v;
+  }
+}
+
 __global__ void finish_info_kernel(int32_t* info) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && *info == 0x7f7f7f7f) *info = 0;
 }
@@ -766,9 +791,21 @@ int cholesky_inverse_upper_on(const float* H, int64_t n, const int64_t* perm, fl
   const int64_t np = c.np;
   int rc = hip_check(hipMemsetAsync(info, 0x7f, 4, s), "hipMemsetAsync(info)");  // 0x7f7f7f7f = "no failure yet"
   if (rc != DCQ_OK) return rc;
-  hipLaunchKernelGGL(flip_pad_kernel, dim3(static_cast<unsigned>((np + 255) / 256), static_cast<unsigned>(np)), dim3(256),
-                     0, s, H, n, perm, diag_add, A, np);
-  DCQ_LAUNCH_CHECK("flip_pad_kernel launch");
+  if (perm != nullptr && n <= kFlipRowLdsFloats) {
+    const size_t lds = static_cast<size_t>(n) * sizeof(float);
+    if (lds > 64 * 1024) {
+      rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(flip_pad_rows_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFlipRowLdsFloats * 4)),
+                     "hipFuncSetAttribute(flip_pad_rows_kernel)");
+      if (rc != DCQ_OK) return rc;
+    }
+    hipLaunchKernelGGL(flip_pad_rows_kernel, dim3(static_cast<unsigned>(np)), dim3(256), lds, s, H, n, perm, diag_add, A, np);
+    DCQ_LAUNCH_CHECK("flip_pad_rows_kernel launch");
+  } else {
+    hipLaunchKernelGGL(flip_pad_kernel, dim3(static_cast<unsigned>((np + 255) / 256), static_cast<unsigned>(np)),
+                       dim3(256), 0, s, H, n, perm, diag_add, A, np);
+    DCQ_LAUNCH_CHECK("flip_pad_kernel launch");
+  }
   hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, s, X, np * np, 0.0f);
   DCQ_LAUNCH_CHECK("fill_kernel launch");
   rc = factor_invert(A, X, T, np, 0, c.nblk, info, s);
