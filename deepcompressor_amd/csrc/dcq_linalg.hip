@@ -49,7 +49,7 @@ struct GemmParams {
   // triangular operands: A(m, k) = 0 for k < m / for k > m; B[k][n] = 0 for k > n (origins on the diagonal)
   int32_t k_above_m, k_below_m, k_below_n;
   int32_t tiles_m, tiles_n;
-  int32_t vec_a, vec_b;  // 16-byte accesses allowed (pointer and leading dimension aligned)
+  int32_t vec_a, vec_b, vec_c;  // 16-byte accesses allowed (pointer and leading dimension aligned)
 };
 
 // One 16-byte piece of a row: `FAST` pieces are whole and aligned; otherwise every element is guarded by `limit`
@@ -220,6 +220,209 @@ static int launch_gemm_variant(const GemmParams& p, hipStream_t s) {
   return DCQ_OK;
 }
 
+// =============================================================================================
+// The same GEMM on the bf16 matrix pipe, for large problems.  A float32 value splits exactly into three bfloat16
+// terms x = h + m + l (3 x 8 significant bits, each the round-to-nearest of what the previous ones left), and a
+// product is accumulated in float32 as  h h' + h m' + m h' + m m' + h l' + l h' : the three terms left out are below
+// 2^-23 |x x'|, the size of one float32 rounding, so the result has float32-GEMM accuracy while six bf16 matrix
+// instructions (16 x the rate of a float32 one each) stand where sixteen float32 ones did.
+//
+// Tile 128 x 128 per workgroup of 4 waves, K step 32.  Waves 0-1 stage the A operand, waves 2-3 the B operand:
+// float32 from global memory into registers (issued one K step ahead), split, written to LDS as three planes of
+// [k chunk of 8][row][8 bf16], the layout both operands of v_mfma_f32_16x16x32_bf16 read with one 16-byte access
+// per lane.  LDS row s of a tile holds the tile's row (or column) 64 (s / 64) + 4 (s % 16) + (s / 16) % 4 (stored at
+// row s ^ chunk, which spreads the 8-byte writes of a row-major A operand over the banks): a thread
+// that loaded 4 consecutive columns of a k-major operand then writes, together with its 15 neighbours, 256
+// contiguous bytes per column (no bank conflict), and in the result a lane holds 4 consecutive columns of C.
+// =============================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSplitK = 32;
+constexpr int kSplitChunkBytes = 128 * 16;                   // [row 128][8 bf16]
+constexpr int kSplitPlaneBytes = 4 * kSplitChunkBytes;       // 4 chunks of 8 = one K step
+constexpr int kSplitOperandBytes = 3 * kSplitPlaneBytes;
+constexpr int kSplitLdsBytes = 2 * kSplitOperandBytes;       // 48 KiB
+
+__device__ __forceinline__ void split_pair(f32x2 v, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+  const f32x2 r1 = v - hf;  // exact
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+  const f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
+  const f32x2 r2 = r1 - mf;  // exact
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
+// 8 consecutive-k values of one row -> the row's 16 bytes in each of the three planes
+__device__ __forceinline__ void split_store(const float (&x)[8], unsigned char* at) {
+  uint4 h, m, l;
+  split_pair(f32x2{x[0], x[1]}, h.x, m.x, l.x);
+  split_pair(f32x2{x[2], x[3]}, h.y, m.y, l.y);
+  split_pair(f32x2{x[4], x[5]}, h.z, m.z, l.z);
+  split_pair(f32x2{x[6], x[7]}, h.w, m.w, l.w);
+  *reinterpret_cast<uint4*>(at) = h;
+  *reinterpret_cast<uint4*>(at + kSplitPlaneBytes) = m;
+  *reinterpret_cast<uint4*>(at + 2 * kSplitPlaneBytes) = l;
+}
+
+__device__ __forceinline__ int split_row_of(int s) { return 64 * (s >> 6) + 4 * (s & 15) + ((s >> 4) & 3); }
+
+template <bool A_KMAJOR, bool FAST>
+__device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned char* lds, int m0, int n0, int k_begin,
+                                                int nk) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const bool stages_a = tid < 128;  // uniform per wave
+  const int u = tid & 127;
+  float4 stage[8];
+  // k-major operand: thread = (4 consecutive columns 4 q.., k chunk kc); row-major A: thread = LDS row u, all 4 chunks
+  const int q = u & 31, kc = u >> 5;
+  auto load_stage = [&](int kt) {
+    const int k0 = k_begin + kt * kSplitK;
+    if (stages_a && !A_KMAJOR) {
+      // 8 lanes read the 128 bytes of one row; a thread holds piece u % 8 of the rows 16 it + u / 8
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = min(m0 + split_row_of(16 * it + (u >> 3)), p.M - 1);
+        stage[it] = load_piece<FAST>(p.A + static_cast<int64_t>(row) * p.lda + k0, 4 * (u & 7), kSplitK);
+      }
+    } else {
+      const float* src = stages_a ? p.A : p.B;
+      const int64_t ld = stages_a ? p.lda : p.ldb;
+      const int c0 = (stages_a ? m0 : n0) + 4 * q, limit = stages_a ? p.M : p.N;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) stage[j] = load_piece<FAST>(src + static_cast<int64_t>(k0 + 8 * kc + j) * ld, c0, limit);
+    }
+  };
+  auto store_stage = [&]() {
+    unsigned char* img = lds + (stages_a ? 0 : kSplitOperandBytes);
+    if (stages_a && !A_KMAJOR) {
+      const int ck = (u & 7) >> 1;  // the piece's k chunk; its half of the chunk: u % 2
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int srow = 16 * it + (u >> 3);
+        const bool live = m0 + split_row_of(srow) < p.M;
+        const float4 v = live ? stage[it] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint2 h, m, l;
+        split_pair(f32x2{v.x, v.y}, h.x, m.x, l.x);
+        split_pair(f32x2{v.z, v.w}, h.y, m.y, l.y);
+        unsigned char* at = img + ck * kSplitChunkBytes + (srow ^ ck) * 16 + (u & 1) * 8;
+        *reinterpret_cast<uint2*>(at) = h;
+        *reinterpret_cast<uint2*>(at + kSplitPlaneBytes) = m;
+        *reinterpret_cast<uint2*>(at + 2 * kSplitPlaneBytes) = l;
+      }
+    } else {
+      // rows (q % 16) + 16 c + 64 (q / 16), c = 0..3; kc only flips the two lowest bits of the row
+      unsigned char* at = img + kc * kSplitChunkBytes + (((q & 15) ^ kc) + 64 * (q >> 4)) * 16;
+      {
+        const float x[8] = {stage[0].x, stage[1].x, stage[2].x, stage[3].x, stage[4].x, stage[5].x, stage[6].x, stage[7].x};
+        split_store(x, at);
+      }
+      {
+        const float x[8] = {stage[0].y, stage[1].y, stage[2].y, stage[3].y, stage[4].y, stage[5].y, stage[6].y, stage[7].y};
+        split_store(x, at + 16 * 16);
+      }
+      {
+        const float x[8] = {stage[0].z, stage[1].z, stage[2].z, stage[3].z, stage[4].z, stage[5].z, stage[6].z, stage[7].z};
+        split_store(x, at + 32 * 16);
+      }
+      {
+        const float x[8] = {stage[0].w, stage[1].w, stage[2].w, stage[3].w, stage[4].w, stage[5].w, stage[6].w, stage[7].w};
+        split_store(x, at + 48 * 16);
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  if (nk > 0) {
+    load_stage(0);
+    store_stage();
+  }
+  __syncthreads();
+  const int g = lane >> 4, j = lane & 15;
+  const unsigned char* fa = lds + g * kSplitChunkBytes + (64 * wr + (j ^ g)) * 16;
+  const unsigned char* fb = lds + kSplitOperandBytes + g * kSplitChunkBytes + (64 * wc + (j ^ g)) * 16;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_stage(kt + 1);
+    bf16x8 a[3][4], b[3][4];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fa + pl * kSplitPlaneBytes + i * 256));
+        b[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fb + pl * kSplitPlaneBytes + i * 256));
+      }
+    // smallest terms first
+    constexpr int pa[6] = {0, 2, 1, 0, 1, 0}, pb[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa[t]][i], b[pb[t]][n], acc[i][n], 0, 0, 0);
+    __syncthreads();  // every wave has read this K step's image
+    if (kt + 1 < nk) store_stage();
+    __syncthreads();
+  }
+  // lane (g, j) of block (i, n) holds C[64 wr + 16 g + 4 r + i][64 wc + 4 j + n], r = 0..3
+  const bool whole = m0 + 128 <= p.M && n0 + 128 <= p.N && p.vec_c;  // uniform
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 64 * wr + 16 * g + 4 * r + i, col = n0 + 64 * wc + 4 * j;
+      float v[4] = {p.alpha * acc[i][0][r], p.alpha * acc[i][1][r], p.alpha * acc[i][2][r], p.alpha * acc[i][3][r]};
+      float* c = p.C + static_cast<int64_t>(row) * p.ldc + col;
+      if (whole) {
+        float4 out = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.beta != 0.0f) {
+          const float4 old = *reinterpret_cast<const float4*>(c);
+          out = make_float4(p.beta * old.x + v[0], p.beta * old.y + v[1], p.beta * old.z + v[2], p.beta * old.w + v[3]);
+        }
+        *reinterpret_cast<float4*>(c) = out;
+      } else if (row < p.M) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col + e < p.N) c[e] = p.beta == 0.0f ? v[e] : p.beta * c[e] + v[e];
+      }
+    }
+}
+
+template <bool A_KMAJOR>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(const GemmParams p) {
+  extern __shared__ __align__(16) unsigned char gemm_smem[];
+  const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+  if (p.upper_only && tn < tm) return;
+  const int m0 = tm * 128, n0 = tn * 128;
+  int k_begin = 0, k_end = p.K;
+  if (p.k_above_m) k_begin = max(k_begin, m0 / kSplitK * kSplitK);
+  if (p.k_below_m) k_end = min(k_end, m0 + 128);
+  if (p.k_below_n) k_end = min(k_end, n0 + 128);
+  const int nk = k_end > k_begin ? (k_end - k_begin) / kSplitK : 0;
+  const bool fast = p.vec_a && p.vec_b && n0 + 128 <= p.N && (!A_KMAJOR || m0 + 128 <= p.M);
+  if (fast) {
+    gemm_split_tile<A_KMAJOR, true>(p, gemm_smem, m0, n0, k_begin, nk);
+  } else {
+    gemm_split_tile<A_KMAJOR, false>(p, gemm_smem, m0, n0, k_begin, nk);
+  }
+}
+
+template <bool A_KMAJOR>
+static int launch_gemm_split(const GemmParams& p, hipStream_t s) {
+  const unsigned grid = static_cast<unsigned>(p.tiles_m) * static_cast<unsigned>(p.tiles_n);
+  hipLaunchKernelGGL(gemm_split_kernel<A_KMAJOR>, dim3(grid), dim3(kGemmThreads), kSplitLdsBytes, s, p);
+  DCQ_LAUNCH_CHECK("gemm_split_kernel launch");
+  return DCQ_OK;
+}
+
 static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s) {
   GemmParams p = pin;
   if (p.M <= 0 || p.N <= 0) return DCQ_OK;
@@ -230,6 +433,8 @@ static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s) {
   const int T = big_tiles < 512 ? 64 : 128;
   p.tiles_m = (p.M + T - 1) / T;
   p.tiles_n = (p.N + T - 1) / T;
+  p.vec_c = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.ldc % 4 == 0;
+  if (T == 128 && p.K % kSplitK == 0) return a_kmajor ? launch_gemm_split<true>(p, s) : launch_gemm_split<false>(p, s);
   if (T == 64) return a_kmajor ? launch_gemm_variant<true, 64>(p, s) : launch_gemm_variant<false, 64>(p, s);
   return a_kmajor ? launch_gemm_variant<true, 128>(p, s) : launch_gemm_variant<false, 128>(p, s);
 }

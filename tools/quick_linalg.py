@@ -17,6 +17,24 @@ def timed(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "err":
+    # accuracy of the large-problem GEMM path against float64, beside torch's float32 GEMM
+    torch.manual_seed(0)
+    for (M, N, K, at) in [(3072, 3072, 1024, False), (3072, 3072, 1024, True), (3000, 3100, 512, False), (3001, 3103, 512, True),
+                          (4096, 13824, 512, False)]:
+        a = torch.randn((K, M) if at else (M, K), device="cuda") * torch.logspace(-3, 3, K, device="cuda").reshape((K, 1) if at else (1, K))
+        b = torch.randn(K, N, device="cuda")
+        c = torch.randn(M, N, device="cuda")
+        am = a.T if at else a
+        ref = c.double() - am.double() @ b.double()
+        scale = (am.double().abs() @ b.double().abs())
+        out = c.clone()
+        gemm_f32(a, b, out, alpha=-1.0, beta=1.0, a_transposed=at)
+        t = c.clone().addmm_(am, b, alpha=-1.0)
+        e_ours = ((out.double() - ref).abs() / scale).max().item()
+        e_torch = ((t.double() - ref).abs() / scale).max().item()
+        print(f"M={M} N={N} K={K} at={at}: max |err| / (|A||B|)  ours {e_ours:.3e}  torch f32 {e_torch:.3e}", flush=True)
+    sys.exit(0)
 only_inv = len(sys.argv) > 1 and sys.argv[1] == "inv"
 sizes = [int(v) for v in sys.argv[2:]] if only_inv else (128, 1024, 4096, 14336)
 for (M, N, K, at) in [] if only_inv else [(4096, 14208, 128, False), (14336, 3968, 128, False), (4096, 4096, 128, False), (4096, 13824, 512, False), (14336, 3584, 512, False),
