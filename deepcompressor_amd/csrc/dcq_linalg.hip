@@ -276,27 +276,27 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
   const int wr = wave >> 1, wc = wave & 1;
   const bool stages_a = tid < 128;  // uniform per wave
   const int u = tid & 127;
-  float4 stage[8];
-  // k-major operand: thread = (4 consecutive columns 4 q.., k chunk kc); row-major A: thread = LDS row u, all 4 chunks
+  // k-major operand: thread = (4 consecutive columns 4 q.., k chunk kc); row-major A: thread = piece u % 8 of 8 rows
+  float4 regs[2][8];  // two sets of staging registers, used in turn: K step kt + 2 is requested while kt is multiplied
   const int q = u & 31, kc = u >> 5;
-  auto load_stage = [&](int kt) {
+  auto load_stage = [&](int kt, const int set) __attribute__((always_inline)) {
     const int k0 = k_begin + kt * kSplitK;
     if (stages_a && !A_KMAJOR) {
       // 8 lanes read the 128 bytes of one row; a thread holds piece u % 8 of the rows 16 it + u / 8
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int row = min(m0 + split_row_of(16 * it + (u >> 3)), p.M - 1);
-        stage[it] = load_piece<FAST>(p.A + static_cast<int64_t>(row) * p.lda + k0, 4 * (u & 7), kSplitK);
+        regs[set][it] = load_piece<FAST>(p.A + static_cast<int64_t>(row) * p.lda + k0, 4 * (u & 7), kSplitK);
       }
     } else {
       const float* src = stages_a ? p.A : p.B;
       const int64_t ld = stages_a ? p.lda : p.ldb;
       const int c0 = (stages_a ? m0 : n0) + 4 * q, limit = stages_a ? p.M : p.N;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) stage[j] = load_piece<FAST>(src + static_cast<int64_t>(k0 + 8 * kc + j) * ld, c0, limit);
+      for (int j = 0; j < 8; ++j) regs[set][j] = load_piece<FAST>(src + static_cast<int64_t>(k0 + 8 * kc + j) * ld, c0, limit);
     }
   };
-  auto store_stage = [&]() {
+  auto store_stage = [&](const int set) __attribute__((always_inline)) {
     unsigned char* img = lds + (stages_a ? 0 : kSplitOperandBytes);
     if (stages_a && !A_KMAJOR) {
       const int ck = (u & 7) >> 1;  // the piece's k chunk; its half of the chunk: u % 2
@@ -304,7 +304,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
       for (int it = 0; it < 8; ++it) {
         const int srow = 16 * it + (u >> 3);
         const bool live = m0 + split_row_of(srow) < p.M;
-        const float4 v = live ? stage[it] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 v = live ? regs[set][it] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         uint2 h, m, l;
         split_pair(f32x2{v.x, v.y}, h.x, m.x, l.x);
         split_pair(f32x2{v.z, v.w}, h.y, m.y, l.y);
@@ -317,19 +317,19 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
       // rows (q % 16) + 16 c + 64 (q / 16), c = 0..3; kc only flips the two lowest bits of the row
       unsigned char* at = img + kc * kSplitChunkBytes + (((q & 15) ^ kc) + 64 * (q >> 4)) * 16;
       {
-        const float x[8] = {stage[0].x, stage[1].x, stage[2].x, stage[3].x, stage[4].x, stage[5].x, stage[6].x, stage[7].x};
+        const float x[8] = {regs[set][0].x, regs[set][1].x, regs[set][2].x, regs[set][3].x, regs[set][4].x, regs[set][5].x, regs[set][6].x, regs[set][7].x};
         split_store(x, at);
       }
       {
-        const float x[8] = {stage[0].y, stage[1].y, stage[2].y, stage[3].y, stage[4].y, stage[5].y, stage[6].y, stage[7].y};
+        const float x[8] = {regs[set][0].y, regs[set][1].y, regs[set][2].y, regs[set][3].y, regs[set][4].y, regs[set][5].y, regs[set][6].y, regs[set][7].y};
         split_store(x, at + 16 * 16);
       }
       {
-        const float x[8] = {stage[0].z, stage[1].z, stage[2].z, stage[3].z, stage[4].z, stage[5].z, stage[6].z, stage[7].z};
+        const float x[8] = {regs[set][0].z, regs[set][1].z, regs[set][2].z, regs[set][3].z, regs[set][4].z, regs[set][5].z, regs[set][6].z, regs[set][7].z};
         split_store(x, at + 32 * 16);
       }
       {
-        const float x[8] = {stage[0].w, stage[1].w, stage[2].w, stage[3].w, stage[4].w, stage[5].w, stage[6].w, stage[7].w};
+        const float x[8] = {regs[set][0].w, regs[set][1].w, regs[set][2].w, regs[set][3].w, regs[set][4].w, regs[set][5].w, regs[set][6].w, regs[set][7].w};
         split_store(x, at + 48 * 16);
       }
     }
@@ -342,15 +342,15 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
     for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
   if (nk > 0) {
-    load_stage(0);
-    store_stage();
+    load_stage(0, 0);
+    if (nk > 1) load_stage(1, 1);
+    store_stage(0);
   }
   __syncthreads();
   const int g = lane >> 4, j = lane & 15;
   const unsigned char* fa = lds + g * kSplitChunkBytes + (64 * wr + (j ^ g)) * 16;
   const unsigned char* fb = lds + kSplitOperandBytes + g * kSplitChunkBytes + (64 * wc + (j ^ g)) * 16;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_stage(kt + 1);
+  auto multiply_step = [&]() __attribute__((always_inline)) {
     bf16x8 a[3][4], b[3][4];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
@@ -368,9 +368,18 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
 #pragma unroll
         for (int n = 0; n < 4; ++n)
           acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa[t]][i], b[pb[t]][n], acc[i][n], 0, 0, 0);
+  };
+  // one K step: multiply the image of step kt, then replace it by step kt + 1 (register set `have`); set `next` takes kt + 2
+  auto step = [&](int kt, const int have, const int next) __attribute__((always_inline)) {
+    if (kt + 2 < nk) load_stage(kt + 2, next);
+    multiply_step();
     __syncthreads();  // every wave has read this K step's image
-    if (kt + 1 < nk) store_stage();
+    if (kt + 1 < nk) store_stage(have);
     __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, 1, 0);
+    if (kt + 1 < nk) step(kt + 1, 0, 1);
   }
   // lane (g, j) of block (i, n) holds C[64 wr + 16 g + 4 r + i][64 wc + 4 j + n], r = 0..3
   const bool whole = m0 + 128 <= p.M && n0 + 128 <= p.N && p.vec_c;  // uniform

@@ -56,7 +56,8 @@ def test_hessian_float32_activations():
 
 @pytest.mark.parametrize("M,N,K,a_t", [(128, 128, 32, False), (96, 200, 128, False), (300, 515, 64, True),
                                        (1024, 2048, 128, False), (257, 129, 256, True), (4, 4, 32, False), (131, 77, 64, True), (131, 77, 64, False),
-                                       (2950, 3075, 64, False), (2950, 3076, 32, True)])
+                                       (2950, 3075, 64, False), (2950, 3076, 32, True), (3000, 2900, 160, False),
+                                       (2901, 3000, 96, True)])
 def test_gemm_f32_matches_float64(M, N, K, a_t):
     """c = beta c + alpha a b on the float32 matrix-core path: ragged M / N edges, both A layouts, strided views."""
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -100,6 +101,30 @@ def test_inverse_factor_matches_float64(n, use_perm):
     rel = ((got - want).abs().max() / want.abs().max()).item()
     assert rel < 2e-4, rel
     resid = (got.T @ got @ s - torch.eye(n, dtype=torch.double)).abs().max().item()
+    assert resid < 5e-3, resid
+
+
+def test_inverse_factor_large_matches_float64():
+    """n = 6016: the size from which the recursion's products run as three-term bf16 splits on the bf16 matrix pipe
+    (triangular operands with clipped k ranges, the upper-only update, both A layouts).  Reference route in float64 on
+    the GPU."""
+    n = 6016
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn(2 * n, n, generator=g, device="cuda") * torch.exp(0.5 * torch.randn(n, generator=g, device="cuda"))
+    h = (x.T @ x) * (2.0 / x.shape[0])
+    del x
+    perm = torch.argsort(h.diagonal(), descending=True)
+    mean = float(h.diagonal().mean())
+    u, tries = cholesky_inverse_upper(h, perm, mean, 0.01, 10)
+    assert tries == 1
+    s = h.double()[perm][:, perm]
+    s.diagonal().add_(0.01 * mean)
+    want = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(s)), upper=True)
+    got = u.double()
+    assert torch.equal(got, got.triu()), "U must be upper triangular"
+    rel = ((got - want).abs().max() / want.abs().max()).item()
+    assert rel < 2e-4, rel
+    resid = (got.T @ got @ s - torch.eye(n, dtype=torch.double, device="cuda")).abs().max().item()
     assert resid < 5e-3, resid
 
 

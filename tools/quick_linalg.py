@@ -35,9 +35,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "err":
         e_torch = ((t.double() - ref).abs() / scale).max().item()
         print(f"M={M} N={N} K={K} at={at}: max |err| / (|A||B|)  ours {e_ours:.3e}  torch f32 {e_torch:.3e}", flush=True)
     sys.exit(0)
-only_inv = len(sys.argv) > 1 and sys.argv[1] == "inv"
+only_inv = len(sys.argv) > 1 and sys.argv[1] in ("inv", "big")
 sizes = [int(v) for v in sys.argv[2:]] if only_inv else (128, 1024, 4096, 14336)
-for (M, N, K, at) in [] if only_inv else [(4096, 14208, 128, False), (14336, 3968, 128, False), (4096, 4096, 128, False), (4096, 13824, 512, False), (14336, 3584, 512, False),
+for (M, N, K, at) in [(7168, 7168, 7168, False), (7168, 7168, 7168, True), (4096, 13824, 512, False)] if sys.argv[1:2] == ["big"] else [] if only_inv else [(4096, 14208, 128, False), (14336, 3968, 128, False), (4096, 4096, 128, False), (4096, 13824, 512, False), (14336, 3584, 512, False),
                       (7168, 7168, 7168, False), (7168, 7168, 7168, True), (2048, 2048, 2048, True),
                       (1024, 1024, 1024, True), (512, 512, 512, False), (128, 14208, 128, True), (128, 128, 128, True)]:
     a = torch.randn((K, M) if at else (M, K), device="cuda")
