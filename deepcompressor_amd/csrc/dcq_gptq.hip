@@ -917,14 +917,17 @@ int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64
       if (rc != DCQ_OK) return rc;
       const int64_t c_end = c0 + bc;
       if (c_end < g_end) {  // the rest of this group, right away (K = 128: a block short of 128 is the last one)
-        rc = dcq_gemm_f32(err_block, group_cols, 0, U + c0 * C + c_end, C, W + c_end, ldw, R, g_end - c_end, kSweepCols,
-                          -1.0f, 1.0f, stream);
+        rc = gemm_f32_on_path(err_block, group_cols, 0, U + c0 * C + c_end, C, W + c_end, ldw, R, g_end - c_end,
+                              kSweepCols, -1.0f, 1.0f, static_cast<hipStream_t>(stream), kGemmFloat32);
         if (rc != DCQ_OK) return rc;
       }
     }
     if (g_end < C) {  // everything right of the group, once (a full group: its blocks are all 128 wide)
-      const int rc = dcq_gemm_f32(Err, group_cols, 0, U + g0 * C + g_end, C, W + g_end, ldw, R, C - g_end, group_cols,
-                                  -1.0f, 1.0f, stream);
+      // the path is chosen from the column count alone: a row's result must not depend on how many rows the call
+      // holds (rows of one weight may be split over processes)
+      const int path = C - g_end >= 2048 ? kGemmSplit : kGemmFloat32;
+      const int rc = gemm_f32_on_path(Err, group_cols, 0, U + g0 * C + g_end, C, W + g_end, ldw, R, C - g_end, group_cols,
+                                      -1.0f, 1.0f, static_cast<hipStream_t>(stream), path);
       if (rc != DCQ_OK) return rc;
     }
   }

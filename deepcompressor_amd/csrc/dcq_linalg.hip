@@ -3,8 +3,9 @@
 //     U = upper factor with U^T U = H^-1        (deepcompressor/quantizer/kernel/gptq.py:215-233)
 // and used for the lazy weight update between sweep blocks (gptq.py:269).
 //
-// v_mfma_f32_32x32x2_f32 is an exact float32 multiply-accumulate chain (no reduced-precision path), so results
-// have plain float32 GEMM accuracy.
+// Small and medium products run on v_mfma_f32_32x32x2_f32, an exact float32 multiply-accumulate chain; large ones
+// run on the bf16 matrix pipe with every float32 operand split exactly into three bfloat16 terms (gemm_split_kernel:
+// six of the nine partial products, the rest is below one float32 rounding).  Both have float32 GEMM accuracy.
 //
 // How U is obtained.  With J the index reversal, factor J H J = R^T R (R upper).  Then H = V V^T with
 // V = J R^T J upper triangular, H^-1 = V^-T V^-1, and by uniqueness of the Cholesky factor U = V^-1 = J R^-T J:
@@ -432,18 +433,21 @@ static int launch_gemm_split(const GemmParams& p, hipStream_t s) {
   return DCQ_OK;
 }
 
-static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s) {
+// `path`: kGemmAuto picks by problem size (results of the two float32 tile sizes are bit-identical; the split path
+// rounds differently), kGemmFloat32 / kGemmSplit force one -- for callers whose results must not depend on M.
+static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s, int path = kGemmAuto) {
   GemmParams p = pin;
   if (p.M <= 0 || p.N <= 0) return DCQ_OK;
   p.vec_a = (reinterpret_cast<uintptr_t>(p.A) & 15u) == 0 && p.lda % 4 == 0;
   p.vec_b = (reinterpret_cast<uintptr_t>(p.B) & 15u) == 0 && p.ldb % 4 == 0;
-  // fewer 128-tiles than twice the compute units: the problem is latency-bound, use 64-tiles
+  p.vec_c = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.ldc % 4 == 0;
+  // fewer 128-tiles than twice the compute units: the problem is latency-bound, use 64-tiles of the float32 kernel
   const int64_t big_tiles = static_cast<int64_t>((p.M + 127) / 128) * ((p.N + 127) / 128);
-  const int T = big_tiles < 512 ? 64 : 128;
+  const bool split = p.K % kSplitK == 0 && (path == kGemmSplit || (path == kGemmAuto && big_tiles >= 512));
+  const int T = split || big_tiles >= 512 ? 128 : 64;
   p.tiles_m = (p.M + T - 1) / T;
   p.tiles_n = (p.N + T - 1) / T;
-  p.vec_c = (reinterpret_cast<uintptr_t>(p.C) & 15u) == 0 && p.ldc % 4 == 0;
-  if (T == 128 && p.K % kSplitK == 0) return a_kmajor ? launch_gemm_split<true>(p, s) : launch_gemm_split<false>(p, s);
+  if (split) return a_kmajor ? launch_gemm_split<true>(p, s) : launch_gemm_split<false>(p, s);
   if (T == 64) return a_kmajor ? launch_gemm_variant<true, 64>(p, s) : launch_gemm_variant<false, 64>(p, s);
   return a_kmajor ? launch_gemm_variant<true, 128>(p, s) : launch_gemm_variant<false, 128>(p, s);
 }
@@ -938,10 +942,10 @@ static int static_scratch_of_current_device(void** out) {
 
 using namespace dcq;
 
-extern "C" {
+namespace dcq {
 
-int dcq_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
-                 int64_t M, int64_t N, int64_t K, float alpha, float beta, dcq_stream_t stream) {
+int gemm_f32_on_path(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, float alpha, float beta, hipStream_t stream, int path) {
   DCQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, DCQ_ERR_ARGUMENT, "negative size");
   if (M == 0 || N == 0) return DCQ_OK;
   DCQ_REQUIRE(A && B && C, DCQ_ERR_ARGUMENT, "NULL buffer");
@@ -959,7 +963,16 @@ int dcq_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, 
   g.K = static_cast<int32_t>(K);
   g.alpha = alpha;
   g.beta = beta;
-  return launch_gemm(g, a_kmajor != 0, static_cast<hipStream_t>(stream));
+  return launch_gemm(g, a_kmajor != 0, stream, path);
+}
+
+}  // namespace dcq
+
+extern "C" {
+
+int dcq_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
+                 int64_t M, int64_t N, int64_t K, float alpha, float beta, dcq_stream_t stream) {
+  return gemm_f32_on_path(A, lda, a_kmajor, B, ldb, C, ldc, M, N, K, alpha, beta, static_cast<hipStream_t>(stream), kGemmAuto);
 }
 
 int64_t dcq_cholesky_workspace_bytes(int64_t n) {

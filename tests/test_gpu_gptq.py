@@ -269,16 +269,18 @@ def test_gptq_ragged_columns_and_progressive():
         assert e_gptq < e_rtn, (cname, e_gptq, e_rtn)
 
 
-def test_gptq_row_shards_equal_unsharded():
+@pytest.mark.parametrize("rows,cols,tokens", [(640, 768, 3000), (384, 3072, 4096)])
+def test_gptq_row_shards_equal_unsharded(rows, cols, tokens):
     """Rows are independent given the shared Hessian: quantizing row slabs separately (what each rank does when one
-    linear is sharded over GPUs) reproduces the unsharded codes bit for bit."""
+    linear is sharded over GPUs) reproduces the unsharded codes bit for bit.  The wide case reaches the lazy updates
+    that run as bf16 splits: which arithmetic an update uses is decided by its column count, never by the rows."""
     from deepcompressor_amd.parallel import row_shard
 
     case = FQ.meta["cases"]["uint4_post_g128_f16s"]
     g = torch.Generator().manual_seed(21)
-    w = (torch.randn(640, 768, generator=g) * 0.02).to(torch.bfloat16).cuda()
-    x = (torch.randn(3000, 768, generator=g) * torch.exp(0.5 * torch.randn(768, generator=g))).to(torch.bfloat16).cuda()
-    cache = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_samples=3000, orig_device=x.device)
+    w = (torch.randn(rows, cols, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    x = (torch.randn(tokens, cols, generator=g) * torch.exp(0.5 * torch.randn(cols, generator=g))).to(torch.bfloat16).cuda()
+    cache = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_samples=tokens, orig_device=x.device)
     q = build_quantizer(case)
     kern = QuantGptqConfig()
     full = q.quantize(w, kernel=kern, inputs=cache, return_with_dequant=False, return_with_quant=True).qdata
