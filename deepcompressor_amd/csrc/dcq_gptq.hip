@@ -94,6 +94,7 @@ constexpr int kRowBytes = kBK * 2;                // 128 B per tile row
 constexpr int kOperandBytes = kTile * kRowBytes;  // 32 KiB
 constexpr int kSyrkThreads = 512;
 constexpr int kPatch = 8;
+constexpr int kDirectMaxC = 8192;  // widest activations the SYRK reads untransposed
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -138,6 +139,7 @@ __device__ __forceinline__ void wait_direct_loads() { __builtin_amdgcn_s_waitcnt
 
 struct SyrkParams {
   const uint16_t* xt;  // [Cp / 256][ktiles][256][64]: blocked transposed copy of X (transpose_pad_kernel)
+  const uint16_t* x;   // direct form: the activations themselves, [T][C] with T % 64 == 0 and C % 256 == 0
   int64_t Tp, ktiles;
   int32_t C, Cp;
   int32_t tiles_per_side;  // Cp / 256
@@ -184,7 +186,21 @@ __global__ void syrk_tile_map_kernel(int2* map, int n, int num_tiles) {
   }
 }
 
-template <int ST>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// Transposing LDS read: the 16 lanes of a group read a block of 4 rows x 16 columns of 16-bit elements (lane 4 q + p
+// supplies the address of row q, columns 4 p .. 4 p + 3) and lane i receives column i of the 4 rows.
+__device__ __forceinline__ uint2 lds_read_transposed(const unsigned char* at) {
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                       (__attribute__((address_space(3))) s16x4*)(at)));
+}
+
+// DIRECT: the operand tiles are staged from the activations as they are, X[token][channel], and the fragments are
+// read from LDS with the transposing read, so no transposed copy of X is made.  The LDS image of a k-tile is then
+// [64 tokens][256 channels]; the 32-byte segment (16 channels) index of a row is XOR-ed with
+// (token % 4) | ((token / 8) % 2) * 4, which puts the 8 rows x 32 bytes that the 32 lanes of a half-wave read at once
+// on all 64 banks.
+template <int ST, bool DIRECT>
 __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams p) {
   extern __shared__ __align__(1024) unsigned char lds[];  // [2 buffers][A, B][32 KiB]
   const int tid = threadIdx.x;
@@ -209,23 +225,34 @@ __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams 
 
   // staging: wave w fills rows [32 w, 32 w + 32) of each operand tile with 4 wave-instructions of 8 rows;
   // lane -> (row = lane / 8, LDS chunk position = lane % 8), global chunk = position ^ ((row >> 1) & 7)
+  // (direct form: wave w fills token rows [8 w, 8 w + 8) with 4 wave-instructions of 2 rows x 512 bytes;
+  // lane -> (row = lane / 32, 16-byte slot = lane % 32), global segment = (slot / 2) ^ swizzle(row))
   const int st_row = lane >> 3, st_pos = lane & 7;
   const uint16_t* a_src[4];
   const uint16_t* b_src[4];
+  const int64_t stage_step = DIRECT ? static_cast<int64_t>(kBK) * p.C : static_cast<int64_t>(kTile) * kBK;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int row = wave * 32 + it * 8 + st_row;
-    const int chunk = st_pos ^ ((row >> 1) & 7);
-    a_src[it] = p.xt + ((static_cast<int64_t>(bi) * p.ktiles + k_begin / kBK) * kTile + row) * kBK + chunk * 8;
-    b_src[it] = p.xt + ((static_cast<int64_t>(bj) * p.ktiles + k_begin / kBK) * kTile + row) * kBK + chunk * 8;
+    if constexpr (DIRECT) {
+      const int krow = wave * 8 + it * 2 + (lane >> 5), slot = lane & 31;
+      const int chan = (((slot >> 1) ^ ((krow & 3) | (((krow >> 3) & 1) << 2))) << 4) + (slot & 1) * 8;
+      a_src[it] = p.x + (k_begin + krow) * p.C + bi * kTile + chan;
+      b_src[it] = p.x + (k_begin + krow) * p.C + bj * kTile + chan;
+    } else {
+      const int row = wave * 32 + it * 8 + st_row;
+      const int chunk = st_pos ^ ((row >> 1) & 7);
+      a_src[it] = p.xt + ((static_cast<int64_t>(bi) * p.ktiles + k_begin / kBK) * kTile + row) * kBK + chunk * 8;
+      b_src[it] = p.xt + ((static_cast<int64_t>(bj) * p.ktiles + k_begin / kBK) * kTile + row) * kBK + chunk * 8;
+    }
   }
+  // either form: a wave fills 4 KiB of each operand image per k-tile, 1 KiB per wave-instruction
 #define DCQ_STAGE(buf, kt)                                                                      \
   do {                                                                                          \
     unsigned char* a_dst = lds + (buf) * 2 * kOperandBytes + wave * 32 * kRowBytes;             \
     unsigned char* b_dst = a_dst + kOperandBytes;                                               \
     _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                          \
-      load_to_lds_16(a_src[it] + static_cast<int64_t>(kt) * (kTile * kBK), a_dst + it * 8 * kRowBytes);  \
-      if (!diag) load_to_lds_16(b_src[it] + static_cast<int64_t>(kt) * (kTile * kBK), b_dst + it * 8 * kRowBytes); \
+      load_to_lds_16(a_src[it] + static_cast<int64_t>(kt) * stage_step, a_dst + it * 8 * kRowBytes);  \
+      if (!diag) load_to_lds_16(b_src[it] + static_cast<int64_t>(kt) * stage_step, b_dst + it * 8 * kRowBytes); \
     }                                                                                           \
   } while (0)
 
@@ -246,6 +273,10 @@ __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams 
   const int frag_row = lane & 15, frag_quarter = lane >> 4;
   const int sw = (frag_row >> 1) & 7;
   const int a_base = (wr * 128 + frag_row) * kRowBytes, b_base = (wc * 64 + frag_row) * kRowBytes;
+  // direct form: lane 16 g + 4 q + pp reads token rows 8 g + q (+ 32 per k-half, + 4 for the fragment's second half),
+  // 8 bytes at column pp of the block's 32-byte segment; swizzle of those rows: q | (g % 2) * 4
+  const int tr_lane = (8 * frag_quarter + (frag_row >> 2)) * 512 + (lane & 3) * 8;
+  const int tr_swz = (frag_row >> 2) | ((frag_quarter & 1) << 2);
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) DCQ_STAGE(buf ^ 1, kt + 1);
@@ -257,29 +288,47 @@ __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams 
       // (the scheduler is pinned to that order: left alone it pairs every read with an immediate wait).
       const int pos0 = ((0 * 4 + frag_quarter) ^ sw) << 4, pos1 = ((1 * 4 + frag_quarter) ^ sw) << 4;
       constexpr int D = 1;  // groups of read-ahead (2 measured no faster)
+      constexpr int RD = DIRECT ? 2 : 1;  // LDS reads per fragment
+      // fragment of 16-row block `blk` (of the wave's 8 or 4) for k-half ks
+      auto read_a = [&](int blk, int ks) __attribute__((always_inline)) -> uint4 {
+        if constexpr (DIRECT) {
+          const unsigned char* at = a_lds + tr_lane + ks * (32 * 512) + (((wr * 8 + blk) ^ tr_swz) << 5);
+          const uint2 lo = lds_read_transposed(at), hi = lds_read_transposed(at + 4 * 512);
+          return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+          return *reinterpret_cast<const uint4*>(a_lds + a_base + blk * 16 * kRowBytes + (ks ? pos1 : pos0));
+        }
+      };
+      auto read_b = [&](int blk, int ks) __attribute__((always_inline)) -> uint4 {
+        if constexpr (DIRECT) {
+          const unsigned char* at = b_lds + tr_lane + ks * (32 * 512) + (((wc * 4 + blk) ^ tr_swz) << 5);
+          const uint2 lo = lds_read_transposed(at), hi = lds_read_transposed(at + 4 * 512);
+          return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+          return *reinterpret_cast<const uint4*>(b_lds + b_base + blk * 16 * kRowBytes + (ks ? pos1 : pos0));
+        }
+      };
       uint4 af[D + 1], bf[2][NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bf[0][n] = *reinterpret_cast<const uint4*>(b_lds + b_base + n * 16 * kRowBytes + pos0);
+      for (int n = 0; n < NT; ++n) bf[0][n] = read_b(n, 0);
 #pragma unroll
-      for (int d = 0; d < D; ++d) af[d] = *reinterpret_cast<const uint4*>(a_lds + a_base + d * 16 * kRowBytes + pos0);
-      __builtin_amdgcn_sched_group_barrier(0x100, NT + D, 0);
+      for (int d = 0; d < D; ++d) af[d] = read_a(d, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, RD * (NT + D), 0);
       static_for<2 * MT>([&](auto gi) {
         constexpr int g = decltype(gi)::value;
         constexpr int ks = g / MT, m = g % MT;
         if constexpr (g + D < 2 * MT) {
           constexpr int ks1 = (g + D) / MT, m1 = (g + D) % MT;
-          af[(g + D) % (D + 1)] =
-              *reinterpret_cast<const uint4*>(a_lds + a_base + m1 * 16 * kRowBytes + (ks1 ? pos1 : pos0));
+          af[(g + D) % (D + 1)] = read_a(m1, ks1);
           if constexpr (m1 == 0) {
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-              bf[1][n] = *reinterpret_cast<const uint4*>(b_lds + b_base + n * 16 * kRowBytes + pos1);
+            for (int n = 0; n < NT; ++n) bf[1][n] = read_b(n, 1);
           }
         }
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = mfma_16x16x32<ST>(af[g % (D + 1)], bf[ks][n], acc[m][n]);
         constexpr int reads = (g + D < 2 * MT) ? ((g + D) % MT == 0 ? 1 + NT : 1) : 0;
-        if constexpr (reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);
+        if constexpr (reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, RD * reads, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
       });
     }
@@ -758,7 +807,13 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
   uint16_t* xt = static_cast<uint16_t*>(workspace);
   int2* tile_map = reinterpret_cast<int2*>(static_cast<unsigned char*>(workspace) + h.xt_bytes);
   float* partial = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + h.xt_bytes + h.map_bytes);
-  {
+  // whole 256-channel panels and whole 64-token k-tiles: the SYRK reads the activations as they are.
+  // Up to kDirectMaxC channels, that is; beyond, the direct form's 512-byte pieces (one per token row, rows tens of
+  // kilobytes apart) cost the SYRK more than the transposed copy's 32 KiB blocks save (C = 14336, T = 262144: the SYRK
+  // alone 45 -> 50 ms against 3 ms of transposing; C = 4096: 4.0 -> 4.1 ms against 0.9 ms).
+  const bool direct =
+      C % kTile == 0 && T % kBK == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && C <= kDirectMaxC;
+  if (!direct) {
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
     DCQ_REQUIRE(aligned || (C % 8) != 0, DCQ_ERR_ARGUMENT, "x must be 16-byte aligned");
     dim3 grid(static_cast<unsigned>(h.Tp / kTrTile), static_cast<unsigned>(h.Cp / kTrTile));
@@ -771,6 +826,7 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
   SyrkParams p{};
   p.tile_map = tile_map;
   p.xt = xt;
+  p.x = static_cast<const uint16_t*>(x);
   p.Tp = h.Tp;
   p.ktiles = h.ktiles;
   p.C = static_cast<int32_t>(C);
@@ -783,7 +839,8 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
   p.H = H;
   p.partial = partial;
   const size_t lds = 2 * 2 * kOperandBytes;
-  auto kern = storage == DCQ_BF16 ? syrk_kernel<DCQ_BF16> : syrk_kernel<DCQ_F16>;
+  auto kern = storage == DCQ_BF16 ? (direct ? syrk_kernel<DCQ_BF16, true> : syrk_kernel<DCQ_BF16, false>)
+                                  : (direct ? syrk_kernel<DCQ_F16, true> : syrk_kernel<DCQ_F16, false>);
   if (lds > 64 * 1024) {
     int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),

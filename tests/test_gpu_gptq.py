@@ -25,8 +25,10 @@ FQ = load_golden("fake_quant")
 
 
 @pytest.mark.parametrize("T,C,dt", [(1024, 512, torch.bfloat16), (777, 200, torch.float16), (4096, 384, torch.bfloat16),
-                                    (16384, 1024, torch.float16)])
+                                    (16384, 1024, torch.float16), (8192, 768, torch.bfloat16), (64, 256, torch.float16)])
 def test_hessian_matches_float64(T, C, dt):
+    """Whole 256-channel panels with whole 64-token tiles are read untransposed (transposing LDS reads); every other
+    shape goes through the padded transposed copy."""
     g = torch.Generator().manual_seed(T + C)
     x = (torch.randn(T, C, generator=g) * torch.exp(torch.randn(C, generator=g))).to(dt)
     x[:, 3] = 0
