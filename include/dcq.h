@@ -260,7 +260,8 @@ int dcq_selftest_division(const float* x, const float* s, float* fast, float* re
  * sqrt(2 / num_samples) (gptq.py:184-194): pass alpha = 2 / num_samples.  Only the upper triangle is
  * computed and mirrored; the result does not depend on launch timing (no atomics).  `workspace` must hold
  * dcq_hessian_workspace_bytes(T, C) bytes (256-byte aligned): a zero-padded transpose of x plus split-K
- * partial tiles.
+ * partial tiles (16-byte aligned x with C a multiple of 256, at most 8192, and T a multiple of 64 is read as it is;
+ * the space for the transpose is then left unused).
  *
  * dcq_gptq_sweep_block: one block (<= 128 columns, the reference's block_size) of the column loop
  * (gptq.py:236-268).  W[R][ldw] is the float32 working weight with columns already permuted by `perm`
