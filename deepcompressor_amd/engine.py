@@ -7,6 +7,7 @@ kernels cannot address directly, and provides the stream.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -23,6 +24,12 @@ __all__ = ["canonical_groups", "group_range", "make_rounding", "make_step", "fak
 
 _ZD = {None: _lib.ZERO_NONE, ZeroPointDomain.PreScale: _lib.ZERO_PRE, ZeroPointDomain.PostScale: _lib.ZERO_POST}
 _TORCH_ROUND = {torch.float32: _lib.ROUND_F32, torch.float16: _lib.ROUND_F16, torch.bfloat16: _lib.ROUND_BF16}
+
+
+# When the quantizer checks its input for NaN / Inf (the reference asserts on the codes of every call,
+# quantizer/impl/base.py:250-251; here the check is one more read of the tensor and a host read):
+# "export" -- calls that return codes, "always", "never".
+FINITE_CHECKS: str = os.environ.get("DCQ_FINITE_CHECKS", "export")
 
 
 def _require_gpu(t: torch.Tensor) -> None:

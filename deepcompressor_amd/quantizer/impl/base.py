@@ -101,6 +101,8 @@ class QuantizerImpl:
             "dynamic_range must have one entry per step")
         if isinstance(kernel, BaseQuantKernelConfig):
             kernel = kernel.build()
+        if kernel is None or type(kernel) is QuantRtnKernel:
+            self._check_finite_input(tensor, scale, dynamic_range, return_with_quant)
         if n_steps > 2:
             return self._quantize_chain(tensor, kernel, scale, zero, dynamic_range, round_delta, return_with_dequant,
                                         return_with_quant, kwargs)
@@ -120,6 +122,25 @@ class QuantizerImpl:
             return self._quantize_two_level(tensor, dr_last, return_with_dequant, return_with_quant)
         return self._quantize_general(tensor, kernel, scale, zero, dynamic_range, round_delta, return_with_dequant,
                                       return_with_quant, kwargs)
+
+    @staticmethod
+    def _check_finite_input(tensor, scale, dynamic_range, want_quant: bool) -> None:
+        """The reference asserts that the codes hold neither NaN nor Inf (impl/base.py:250-251).  The round-to-nearest
+        kernels here clamp with min / max instructions, which drop a NaN operand, so their codes cannot show it; the
+        condition is checked where it arises: a NaN anywhere in the input gives the reference NaN codes, and so does
+        an Inf when the step's range is taken from the data (Inf / Inf).  One extra read of the tensor and one host
+        read, so by default (``engine.FINITE_CHECKS == "export"``) only calls that hand back codes pay it;
+        ``"always"`` checks every call as the reference does, ``"never"`` none."""
+        policy = engine.FINITE_CHECKS
+        if policy == "never" or (policy != "always" and not want_quant):
+            return
+        if bool(torch.isfinite(tensor).all()):
+            return
+        assert not tensor.isnan().any(), "Quantized tensor contains NaN."
+        from_data = all(s is None for s in scale) and all(
+            d is None or (d.max is None and not isinstance(d.ratio, torch.Tensor)) for d in dynamic_range)
+        if from_data:
+            raise AssertionError("Quantized tensor contains NaN.")  # the reference's Inf / Inf
 
     # ---- fused path --------------------------------------------------------------------------
     def _quantize_fused(self, tensor, dyn, want_dequant, want_quant) -> QuantTensor:

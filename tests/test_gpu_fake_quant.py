@@ -92,6 +92,30 @@ def test_empty_and_cpu_inputs_fail_loudly():
         q.quantize(torch.zeros(4, 128, dtype=torch.bfloat16))
 
 
+@pytest.mark.parametrize("cname", ["uint4_post_g128_f16s", "nvfp4_g16", "qoq_g128"])
+def test_nan_and_inf_inputs_are_refused_like_the_reference(cname, monkeypatch):
+    """The reference asserts 'Quantized tensor contains NaN / Inf' on the codes (impl/base.py:250-251): a NaN input
+    always ends there, an Inf input when the range comes from the data (Inf / Inf).  Calls that return codes check by
+    default, every call under the "always" policy, none under "never"."""
+    from deepcompressor_amd import engine
+    q = build_quantizer(FQ.meta["cases"][cname])
+    g = torch.Generator().manual_seed(9)
+    w = (torch.randn(32, 512, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    for bad in (float("nan"), float("inf")):
+        wb = w.clone()
+        wb[5, 77] = bad
+        with pytest.raises(AssertionError, match="Quantized tensor contains"):
+            q.quantize(wb, return_with_dequant=False, return_with_quant=True)
+        q.quantize(wb)  # dequantized values only: unchecked by default
+        monkeypatch.setattr(engine, "FINITE_CHECKS", "always")
+        with pytest.raises(AssertionError, match="Quantized tensor contains"):
+            q.quantize(wb)
+        monkeypatch.setattr(engine, "FINITE_CHECKS", "never")
+        q.quantize(wb, return_with_dequant=False, return_with_quant=True)
+        monkeypatch.setattr(engine, "FINITE_CHECKS", "export")
+    q.quantize(w, return_with_dequant=False, return_with_quant=True)
+
+
 def test_codebook_round_matches_oracle():
     from deepcompressor_amd.data.dtype import QuantDataType
     g = torch.Generator().manual_seed(0)
