@@ -289,10 +289,14 @@ def _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache, 
             if isinstance(result.zero, torch.Tensor):
                 zeros.append((f"{param_name}.{zero_name}", result.zero))
     def copy_to_host() -> None:
+        # every copy queued, then one wait for all of them (page-locked destinations)
         for name, quantizer in searched.items():
-            quantizer_state_dict[name] = quantizer.state_dict()
+            quantizer_state_dict[name] = quantizer.state_dict(non_blocking=True)
         for key, zero in zeros:
-            scale_state_dict[key] = zero.to("cpu")
+            scale_state_dict[key] = (torch.empty(zero.shape, dtype=zero.dtype, pin_memory=True).copy_(
+                zero, non_blocking=True) if zero.is_cuda else zero.clone())
+        if torch.cuda.is_available() and (searched or zeros):
+            torch.cuda.current_stream().synchronize()
 
     if host_copies is None:
         copy_to_host()

@@ -196,8 +196,18 @@ class Quantizer(QuantizerImpl):
             branches.append(lb)
         return qtensors, branches
 
-    def state_dict(self, device: torch.device | str = "cpu") -> dict[str, tp.Any]:
-        copy = lambda t: t.to(device).clone()  # noqa: E731
+    def state_dict(self, device: torch.device | str = "cpu", non_blocking: bool = False) -> dict[str, tp.Any]:
+        """quantizer/processor.py:312-339.  ``non_blocking`` (no counterpart in the reference): device tensors bound
+        for the host are copied asynchronously into page-locked memory on the current stream; the caller synchronises
+        that stream once before reading any of them, instead of once per tensor."""
+        to_pinned = non_blocking and torch.device(device).type == "cpu"
+
+        def copy(t: torch.Tensor) -> torch.Tensor:
+            if to_pinned and t.is_cuda:
+                host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                return host.copy_(t, non_blocking=True)
+            return t.to(device).clone()
+
         if self.dynamic_range is None:
             dyn = None
         elif isinstance(self.dynamic_range, DynamicRange):
