@@ -116,6 +116,8 @@ def lib():
         handle.dcq_cholesky_workspace_bytes.restype = C.c_int64
         handle.dcq_profile_next_hessian.argtypes = [_p, _p]
         handle.dcq_profile_next_hessian.restype = None
+        handle.dcq_hessian_round_width.argtypes = [_i32]
+        handle.dcq_hessian_round_width.restype = None
         handle.dcq_version.restype = C.c_char_p
         handle.dcq_last_error.restype = C.c_char_p
         _lib = handle

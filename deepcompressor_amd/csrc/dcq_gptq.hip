@@ -411,6 +411,7 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkParams p) {
 }
 
 static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+static thread_local int g_round_width = 0;  // workgroups per SYRK round asked for by this thread (0: one per compute unit)
 
 static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
@@ -778,6 +779,8 @@ int dcq_debug_read_stamps(unsigned long long* out) {
 }
 #endif
 
+void dcq_hessian_round_width(int32_t workgroups) { g_round_width = workgroups > 0 ? workgroups : 0; }
+
 void dcq_profile_next_hessian(void* start, void* stop) {
   g_prof_start = static_cast<hipEvent_t>(start);
   g_prof_stop = static_cast<hipEvent_t>(stop);
@@ -860,6 +863,7 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8)
       per_launch = cus / 8 * 8;  // whole groups of 8: workgroup i runs on XCD i mod 8
   }
+  if (g_round_width >= 8 && g_round_width < per_launch) per_launch = g_round_width / 8 * 8;
   for (int first = 0; first < total; first += per_launch) {
     p.first_logical = first;
     const int n = total - first < per_launch ? total - first : per_launch;

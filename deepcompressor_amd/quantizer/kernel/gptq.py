@@ -98,7 +98,7 @@ def clear_hessian_cache() -> None:
         _prepared.clear()
 
 
-def prepare_hessians(caches, device: torch.device, world: int = 1) -> list[torch.Tensor]:
+def prepare_hessians(caches, device: torch.device, world: int = 1, round_width: int = 0) -> list[torch.Tensor]:
     """Compute the Hessian of every activation cache in ``caches`` now, one after the other on the current stream
     (each launch has the whole chip), and keep them for ``hessian_of`` calls from any thread until
     ``clear_hessian_cache``.  The pipelines that consume them (inverse factor, sweeps) are latency-bound and may then
@@ -107,9 +107,20 @@ def prepare_hessians(caches, device: torch.device, world: int = 1) -> list[torch
     ``world`` > 1: the calibration tokens are sharded over the processes of the default group (every rank passes the
     cache of its own shard).  H is a sum over tokens, so each rank accumulates its shard with the weight 2 / (total
     number of samples) and the partial Hessians are all-reduced: every rank ends up with the same full H (the same
-    as unsharded up to the order of the float32 sums)."""
+    as unsharded up to the order of the float32 sums).
+
+    ``round_width`` > 0: the SYRK takes at most that many compute units at a time (``dcq_hessian_round_width``), for
+    Hessians computed while latency-bound kernels of other streams need a free compute unit to start on."""
     from ...parallel import all_reduce_sum
 
+    lib().dcq_hessian_round_width(int(round_width))
+    try:
+        return _prepare_hessians(caches, device, world, all_reduce_sum)
+    finally:
+        lib().dcq_hessian_round_width(0)
+
+
+def _prepare_hessians(caches, device, world, all_reduce_sum) -> list[torch.Tensor]:
     out = []
     for inputs in caches:
         key = _inputs_key(inputs, device)

@@ -289,6 +289,13 @@ int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C);
  * handles, created by the caller with timing enabled), then forgets them.  Pass NULLs to disarm. */
 void dcq_profile_next_hessian(void* start, void* stop);
 
+/* Scheduling hint (no reference counterpart): dcq_hessian_accumulate calls of the calling thread launch their
+ * matrix-core kernel in rounds of at most `workgroups` workgroups (rounded down to a multiple of 8, one per XCD in
+ * turn) instead of one per compute unit, which leaves the other compute units to kernels of other streams: a
+ * Hessian that runs beside latency-bound single-workgroup kernels otherwise holds every compute unit until a
+ * workgroup of its round ends.  0 restores the default.  Results do not depend on it. */
+void dcq_hessian_round_width(int32_t workgroups);
+
 int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C, float alpha, float* H, void* workspace,
                            int64_t workspace_bytes, dcq_stream_t stream);
 
