@@ -153,35 +153,42 @@ struct SyrkParams {
   const int2* tile_map;  // [num_tiles] (bi, bj) in patch-major order
 };
 
-// tile_map[l] = l-th tile when the upper triangle is walked patch by patch (8 x 8 tiles, patches row-major,
-// tiles inside a patch row-major; diagonal patches keep only bi <= bj)
+// tile_map[l] = l-th tile when the upper triangle is walked patch by patch (8 x 8 tiles; tiles inside a patch
+// row-major; diagonal patches keep only bi <= bj).  Whole off-diagonal patches come first, then the ragged
+// off-diagonal ones at the matrix edge, then the diagonal patches: a whole patch is 64 tiles, so every aligned
+// window of kWindow = 32 consecutive tiles of the first class is a 4 x 8 half patch that needs 12 operand panels.
+constexpr int kWindow = 32;  // tiles per window = workgroups of an XCD in a round of one workgroup per compute unit
 __global__ void syrk_tile_map_kernel(int2* map, int n, int num_tiles) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= num_tiles) return;
   const int P = (n + kPatch - 1) / kPatch;
   int rem = l;
-  for (int pi = 0; pi < P; ++pi) {
-    const int mi = min(kPatch, n - pi * kPatch);
-    for (int pj = pi; pj < P; ++pj) {
-      const int mj = min(kPatch, n - pj * kPatch);
-      const int count = pi == pj ? mi * (mi + 1) / 2 : mi * mj;
-      if (rem < count) {
-        int i, j;
-        if (pi == pj) {
-          i = 0;
-          while (rem >= mi - i) {
-            rem -= mi - i;
-            ++i;
+  for (int cls = 0; cls < 3; ++cls) {
+    for (int pi = 0; pi < P; ++pi) {
+      const int mi = min(kPatch, n - pi * kPatch);
+      for (int pj = pi; pj < P; ++pj) {
+        const int mj = min(kPatch, n - pj * kPatch);
+        const int kind = pi == pj ? 2 : (mi == kPatch && mj == kPatch ? 0 : 1);
+        if (kind != cls) continue;
+        const int count = pi == pj ? mi * (mi + 1) / 2 : mi * mj;
+        if (rem < count) {
+          int i, j;
+          if (pi == pj) {
+            i = 0;
+            while (rem >= mi - i) {
+              rem -= mi - i;
+              ++i;
+            }
+            j = i + rem;
+          } else {
+            i = rem / mj;
+            j = rem % mj;
           }
-          j = i + rem;
-        } else {
-          i = rem / mj;
-          j = rem % mj;
+          map[l] = make_int2(pi * kPatch + i, pj * kPatch + j);
+          return;
         }
-        map[l] = make_int2(pi * kPatch + i, pj * kPatch + j);
-        return;
+        rem -= count;
       }
-      rem -= count;
     }
   }
 }
@@ -210,8 +217,22 @@ __global__ __launch_bounds__(kSyrkThreads, 1) void syrk_kernel(const SyrkParams 
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r8 = nwg & 7;
   const int logical =
       p.first_logical + (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (blockIdx.x >> 3);
-  const int split = logical / p.num_tiles;
-  const int tile_idx = logical - split * p.num_tiles;
+  // Work items in (split, tile) order, except that the tiles behind the last whole window of kWindow tiles come after
+  // the whole windows of all splits: every split then starts on a window boundary, so the workgroups an XCD gets in a
+  // round are an aligned window (a 4 x 8 half patch: 12 operand panels) in every split, not only in the first, and
+  // the XCDs of a round still work on neighbouring patches of the same range of k (which they share below the L2s).
+  int split, tile_idx;
+  {
+    const int whole = p.num_tiles / kWindow * kWindow, rest = p.num_tiles - whole;
+    if (logical < whole * p.splits) {
+      split = logical / whole;
+      tile_idx = logical - split * whole;
+    } else {
+      const int l2 = logical - whole * p.splits;
+      split = l2 / rest;
+      tile_idx = whole + (l2 - split * rest);
+    }
+  }
   const int2 t = p.tile_map[tile_idx];
   const int bi = t.x, bj = t.y;
   const bool diag = bi == bj;
