@@ -365,9 +365,10 @@ class DynamicRangeCalibrator:
             self.best_range.ratio = torch.full(size=self.ratio_shape, fill_value=ratio, device=device,
                                                dtype=self.develop_dtype)
             return
+        # (masked selections on the device: indexing with a boolean mask would drain the stream for every candidate)
         pos = error < self.best_error  # strict: the earlier (larger) ratio wins ties
-        self.best_error[pos] = error[pos]
-        self.best_range.ratio[pos.view(self.ratio_shape)] = ratio
+        self.best_error = torch.where(pos, error, self.best_error)
+        self.best_range.ratio.masked_fill_(pos.view(self.ratio_shape), ratio)
         if not clamp_based:
             return
         if self.granularity == SearchBasedCalibGranularity.Group:
@@ -376,9 +377,9 @@ class DynamicRangeCalibrator:
             rpos = pos.view(self.pos_view_shape).expand(*self.range_shape)
         else:
             rpos = pos.view([1] * len(self.range_shape)).expand(*self.range_shape)
-        self.best_range.max[rpos] = candidate.max.expand(self.range_shape)[rpos]
+        self.best_range.max = torch.where(rpos, candidate.max.expand(self.range_shape), self.best_range.max)
         if isinstance(candidate.min, torch.Tensor):
-            self.best_range.min[rpos] = candidate.min.expand(self.range_shape)[rpos]
+            self.best_range.min = torch.where(rpos, candidate.min.expand(self.range_shape), self.best_range.min)
 
     def get_best(self) -> DynamicRange:
         """calib/range.py:152-164."""

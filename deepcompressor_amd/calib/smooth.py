@@ -117,10 +117,9 @@ def get_smooth_scale(*, alpha_base: torch.Tensor, beta_base: torch.Tensor, alpha
             smooth_scale = smooth_scale.div_(power(beta_base, beta))
     else:
         smooth_scale = power(beta_base, -beta)
-    smooth_scale[smooth_scale == 0] = 1
-    if smooth_scale.isnan().any() or smooth_scale.isinf().any():
-        smooth_scale = smooth_scale.fill_(1)
-    return smooth_scale
+    # (selected on the device: host-side tests would drain the stream for every candidate of a search)
+    smooth_scale = smooth_scale.masked_fill_(smooth_scale == 0, 1)
+    return torch.where(torch.isfinite(smooth_scale).all(), smooth_scale, torch.ones_like(smooth_scale))
 
 
 def _head_reduce(span: torch.Tensor, unique_heads: int, repeats: int, use_max: bool) -> torch.Tensor:
@@ -263,10 +262,11 @@ class SmoothCalibrator:
         key/value head are added first, so those heads switch together."""
         if best_error is None:
             return error, scale
+        # (selections stay on the device: a host-side comparison would drain the stream once per candidate)
         if numel == 1:
-            if all(bool(e <= b) for b, e in zip(best_error, error, strict=True)):
-                return error, scale
-            return best_error, best_scale
+            take = torch.stack([(e <= b).reshape(()) for b, e in zip(best_error, error, strict=True)]).all()
+            return ([torch.where(take, e, b) for b, e in zip(best_error, error, strict=True)],
+                    torch.where(take, scale, best_scale))
         assert num_channels % numel == 0
         group_size, num_groups = num_channels // numel, numel
         shared = num_heads > 1 and num_head_repeats > 1
@@ -295,11 +295,9 @@ class SmoothCalibrator:
                 pos = pos & (e < b).expand(uniques, repeats, groups_per_head).reshape_as(pos)
             else:
                 pos = pos & (e < b)
-        for b, e in zip(best_error, error, strict=True):
-            b[pos] = e[pos]
+        best_error = [torch.where(pos.view_as(b), e, b) for b, e in zip(best_error, error, strict=True)]
         pos = pos.view(num_groups, 1).expand(num_groups, group_size)
-        best_scale = best_scale.view(num_groups, group_size)
-        best_scale[pos] = scale.view(num_groups, group_size)[pos]
+        best_scale = torch.where(pos, scale.view(num_groups, group_size), best_scale.view(num_groups, group_size))
         return best_error, best_scale
 
     def tell(self, error: list[torch.Tensor]) -> None:
