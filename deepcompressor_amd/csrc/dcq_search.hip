@@ -205,25 +205,29 @@ __global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const S
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) {  // uniform over the wave
           done = true;
           const float y = refined_rcp(sz.s);
-          const f32x2 z2 = {sz.z, sz.z}, s2 = {sz.s, sz.s}, lo2 = {st.tensor.lo, st.tensor.lo}, hi2 = {st.tensor.hi, st.tensor.hi};
+          const f32x2 z2 = {sz.z, sz.z}, s2 = {sz.s, sz.s};
 #pragma unroll
           for (int i = 0; i < NPL; i += 2) {
             const f32x2 xv = {x[i], x[i + 1]};
             f32x2 t = ZD == DCQ_ZERO_POST_SCALE ? xv + z2 : xv;
             t = div_hoisted2(t, sz.s, y);
             if (ZD == DCQ_ZERO_PRE_SCALE) t = t + z2;
-            f32x2 q = {rintf(t.x), rintf(t.y)};
-            q = __builtin_elementwise_min(__builtin_elementwise_max(q, lo2), hi2);
+            // med3 == min(max(v, lo), hi) for the finite values the guard above admits: one instruction, not two
+            const f32x2 q = {__builtin_amdgcn_fmed3f(rintf(t.x), st.tensor.lo, st.tensor.hi),
+                             __builtin_amdgcn_fmed3f(rintf(t.y), st.tensor.lo, st.tensor.hi)};
             f32x2 d;
             if (ZD == DCQ_ZERO_PRE_SCALE) d = (q - z2) * s2;
             else if (ZD == DCQ_ZERO_POST_SCALE) d = q * s2 - z2;
             else d = q * s2;
             const f32x2 dq = from_bits16x2<ST>(to_bits16x2<ST>(d));          // Q(w) in the weight dtype
-            const uint32_t eb = to_bits16x2<ST>(dq - xv) & 0x7fff7fffu;      // |Q(w) - w| in the weight dtype
+            const uint32_t eraw = to_bits16x2<ST>(dq - xv);                  // Q(w) - w in the weight dtype, two values
             if (POW == kPowTable) {
-              pw[i] = from_bits16<ST>(table[eb & 0xffffu]);
-              pw[i + 1] = from_bits16<ST>(table[eb >> 16]);
+              // |.| and the table's two-byte stride in the same mask: byte offset = (bits & 0x7fff) * 2
+              const unsigned char* tb = reinterpret_cast<const unsigned char*>(table);
+              pw[i] = from_bits16<ST>(*reinterpret_cast<const uint16_t*>(tb + ((eraw << 1) & 0xfffeu)));
+              pw[i + 1] = from_bits16<ST>(*reinterpret_cast<const uint16_t*>(tb + ((eraw >> 15) & 0xfffeu)));
             } else {
+              const uint32_t eb = eraw & 0x7fff7fffu;                        // |Q(w) - w|
               const f32x2 a = from_bits16x2<ST>(eb);
               const f32x2 sq = from_bits16x2<ST>(to_bits16x2<ST>(a * a));
               pw[i] = sq.x;
