@@ -63,6 +63,31 @@ def test_range_search_golden(tag):
         assert_bit_equal(to_np(best.min), RS[f"{tag}|min"], "best min")
 
 
+@pytest.mark.parametrize("cname,dt", [("sint4_g128_f16s", "bf16"), ("uint4_post_g128_f16s", "bf16"),
+                                      ("uint4_pre_g128_f16s", "f16"), ("sint4_g128_f16s", "f16")])
+def test_range_search_on_rounding_ties(cname, dt):
+    """Weights on a half-unit grid: with the group maximum at the top code, x / scale lands exactly on k + 0.5 for a
+    large share of the elements and candidates (round-half-to-even decides the code), and within a few units in the
+    last place of it for others -- the cases where an approximate quotient would pick the other code."""
+    case = FQ.meta["cases"][cname]
+    g = torch.Generator().manual_seed(7)
+    top = 7.0 if cname.startswith("sint4") else 7.5
+    w = torch.randint(-15, 16, (96, 1024), generator=g).float() * 0.5
+    w = w.clamp_(-top, top)
+    w[:, ::128] = top      # every group's maximum
+    w[:, 1::128] = -top    # and minimum
+    w = w * torch.tensor([1.0, 0.5, 3.0, 0.0625, 1.0 / 3.0, 1e-3]).repeat(16).view(96, 1)
+    wt = w.to({"bf16": torch.bfloat16, "f16": torch.float16}[dt])
+    ratios = qo.range_ratios(100, 0.2, 1.0)
+    want = qo.range_search_group(wt.float().numpy(), dt, qo.spec_from_case(case), ratios, 2.4)
+    q = build_quantizer(case)
+    out = calibrate_dynamic_range(TensorType.Weights, _config(2.4, 100), True, q, modules=[None], activations=None,
+                                  weights=[nn.Parameter(wt.cuda(), requires_grad=False)])
+    assert_bit_equal(to_np(out[0].max), want["max"], "max")
+    if want["min"] is not None:
+        assert_bit_equal(to_np(out[0].min), want["min"], "min")
+
+
 @pytest.mark.parametrize("cname,dt,degree", [("sint4_g128_f16s", "bf16", 2.4), ("uint4_post_g128_f16s", "f16", 2.4),
                                              ("sint4_g64_defs", "bf16", 2), ("uint4_pre_g128_f16s", "bf16", 2.4)])
 def test_range_search_vs_oracle_random(cname, dt, degree):
