@@ -112,11 +112,13 @@ __global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const S
   constexpr int ROWS = NV / 4;
   static_assert(!PAIR || NPL % 2 == 0, "16-bit groups must be a multiple of 16 elements");
 
+  // The power table is a static array: its LDS address is then a constant the compiler folds into the reads' offset
+  // field (behind the dynamic array's base it costs one address add per read, a twentieth of the kernel's
+  // instructions).  64 KiB is the most a static array may take; the rest is dynamic.
+  __shared__ __align__(16) uint16_t table[POW == kPowTable ? kTableEntries : 8];
   extern __shared__ __align__(16) unsigned char smem[];
-  uint16_t* table = reinterpret_cast<uint16_t*>(smem);
-  constexpr int kTableBytes = POW == kPowTable ? kTableEntries * 2 : 0;
-  float* cbs = reinterpret_cast<float*>(smem + kTableBytes);  // [3][256] codebooks
-  unsigned char* stage = smem + kTableBytes + 3 * 256 * 4;
+  float* cbs = reinterpret_cast<float*>(smem);  // [3][256] codebooks
+  unsigned char* stage = smem + 3 * 256 * 4;
 
   const dcq_step& st = p.step;
   if (POW == kPowTable) {
@@ -450,8 +452,8 @@ static int launch_search(const SearchParams& p, hipStream_t stream) {
   constexpr int EB = sizeof(typename Storage<ST>::elem_t);
   constexpr int kSearchBlock = search_block(NPL);
   constexpr int kGroupsPerBlock = kSearchBlock / kTeam;
-  const size_t lds = (POW == kPowTable ? kTableEntries * 2 : 0) + 3 * 256 * 4 +
-                     static_cast<size_t>(kSearchBlock / kWave) * kGroupsPerWave * (NPL * kTeam * EB + 16);
+  // dynamic part (the kernel's power table is static)
+  const size_t lds = 3 * 256 * 4 + static_cast<size_t>(kSearchBlock / kWave) * kGroupsPerWave * (NPL * kTeam * EB + 16);
   int64_t blocks = (p.G + kGroupsPerBlock - 1) / kGroupsPerBlock;
   if (blocks > 256) blocks = 256;
   const bool int_q = p.step.tensor.kind == DCQ_ROUND_INT;
