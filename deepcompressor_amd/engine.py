@@ -20,7 +20,7 @@ from .data.zero import ZeroPointDomain
 
 __all__ = ["canonical_groups", "group_range", "make_rounding", "make_step", "fake_quant_fused", "range_to_scale",
            "scale_level", "scale_join", "zero_point", "quantize_groups", "dequantize_groups", "simple_round",
-           "pow_table", "range_search_groups"]
+           "pow_table", "range_search_groups", "gather_columns"]
 
 _ZD = {None: _lib.ZERO_NONE, ZeroPointDomain.PreScale: _lib.ZERO_PRE, ZeroPointDomain.PostScale: _lib.ZERO_POST}
 _TORCH_ROUND = {torch.float32: _lib.ROUND_F32, torch.float16: _lib.ROUND_F16, torch.bfloat16: _lib.ROUND_BF16}
@@ -280,6 +280,26 @@ def assert_finite(values: torch.Tensor, what: str, *, inf_first: bool = False) -
     checks = [(values.isnan, "NaN"), (values.isinf, "Inf")]
     for probe, name in (reversed(checks) if inf_first else checks):
         assert not probe().any(), f"{what} contains {name}."
+
+
+def gather_columns(src: torch.Tensor, index: torch.Tensor, zero_columns: torch.Tensor | None = None) -> torch.Tensor:
+    """``torch.where(zero_columns, 0, src)[:, index]`` for a float32 matrix (``zero_columns``: bool per source column),
+    one pass with each row staged in LDS; shapes the kernel does not take (rows that are not a multiple of 4 long or
+    longer than 36864) go through the torch expression."""
+    _require_gpu(src)
+    assert src.ndim == 2 and src.dtype == torch.float32 and index.dtype == torch.int64 and index.numel() == src.shape[1]
+    R, Cn = src.shape
+    src = src.contiguous()
+    if Cn % 4 or Cn > 36864 or src.data_ptr() % 16:
+        if zero_columns is not None:
+            src = torch.where(zero_columns, torch.zeros((), device=src.device, dtype=src.dtype), src)
+        return src[:, index].contiguous()
+    index = index.contiguous()
+    mask = None if zero_columns is None else zero_columns.contiguous().view(torch.uint8)
+    out = torch.empty_like(src)
+    check(lib().dcq_gather_columns(ptr(src), Cn, R, Cn, ptr(index), ptr(mask), ptr(out), Cn, stream_of(src.device)),
+          "dcq_gather_columns")
+    return out
 
 
 def scale_join(a: torch.Tensor, b: torch.Tensor | None, *, fix_zero: bool) -> torch.Tensor:

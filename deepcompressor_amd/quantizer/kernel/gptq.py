@@ -402,7 +402,7 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     attempt = 0
     while True:
         dead, perm, inverse_perm, U, info = _inverse_factor_of(hessian, gptq_config, attempt)
-        Wp = torch.where(dead, torch.zeros((), device=dev, dtype=W.dtype), W)[:, perm].contiguous()
+        Wp = engine.gather_columns(W, perm, zero_columns=dead)  # dead channels zeroed, act-order (gptq.py:199-208)
         Q = torch.zeros_like(Wp)
         check(lib().dcq_gptq_sweep(C.byref(step), ptr(Wp), Cn, R, Cn, ptr(U), ptr(s2), ptr(z2), z_scalar, rg_size,
                                    cg_size, n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, stream_of(dev)),
@@ -415,6 +415,6 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
             break
         attempt += 1
         assert attempt < gptq_config.num_inv_tries, "Hessian could not be factorised"
-    Q = Q[:, inverse_perm]
+    Q = engine.gather_columns(Q, inverse_perm)
     engine.assert_finite(Q, "GPTQ Quantized tensor")
     return Q.reshape(n_rg, rg_size, n_cg, cg_size).contiguous()

@@ -334,3 +334,20 @@ def test_run_on_streams_propagates_errors():
 
     with pytest.raises(ValueError, match="boom"):
         run_on_streams([lambda: torch.ones(4, device="cuda"), bad])
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 512), (33, 14336), (5, 36864), (7, 130), (16, 40960)])
+def test_gather_columns_equals_the_indexing_expression(rows, cols):
+    """The act-order gathers around the sweep (W[:, perm] with dead columns zeroed, Q[:, inverse_perm]) through the
+    LDS-staged kernel, and through the torch expression for the shapes the kernel does not take."""
+    from deepcompressor_amd import engine
+    g = torch.Generator().manual_seed(rows * 131 + cols)
+    src = torch.randn(rows, cols, generator=g).cuda()
+    perm = torch.randperm(cols, generator=g).cuda()
+    dead = (torch.rand(cols, generator=g) < 0.05).cuda()
+    want = torch.where(dead, torch.zeros((), device="cuda"), src)[:, perm]
+    got = engine.gather_columns(src, perm, zero_columns=dead)
+    assert got.is_contiguous() and torch.equal(got, want)
+    inverse = torch.argsort(perm)
+    assert torch.equal(engine.gather_columns(got, inverse), want[:, inverse])
+    assert torch.equal(engine.gather_columns(src, inverse), src[:, inverse])
