@@ -534,6 +534,25 @@ static unsigned small_grid(int64_t n) {
   return static_cast<unsigned>(b);
 }
 
+// flags |= 1 when any x[i] is NaN, |= 2 when any is +-Inf; one read of x (float32), 16-byte loads, one atomic per wave
+// that saw something
+__global__ __launch_bounds__(256) void nonfinite_flags_kernel(const float* x, int64_t n, int32_t* flags) {
+  const int64_t n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  uint32_t seen = 0;
+  auto look = [&](float v) {
+    const uint32_t b = __float_as_uint(v) & 0x7fffffffu;
+    seen |= b > 0x7f800000u ? 1u : (b == 0x7f800000u ? 2u : 0u);
+  };
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    const float4 v = x4[i];
+    look(v.x), look(v.y), look(v.z), look(v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) look(x[n4 * 4 + threadIdx.x]);
+  if (seen) atomicOr(flags, static_cast<int32_t>(seen));
+}
+
 }  // namespace dcq
 
 // =============================================================================================
@@ -915,6 +934,19 @@ int dcq_dequantize_groups(const dcq_step* step, const float* codes, int64_t G, i
   p.deq_hi = deq_hi;
   p.dequant = dequant;
   return dispatch_storage<kDequantOnly>(p, DCQ_F32, out_storage, static_cast<hipStream_t>(stream));
+}
+
+int dcq_nonfinite_flags(const float* x, int64_t n, int32_t* flags, dcq_stream_t stream) {
+  DCQ_REQUIRE(n >= 0 && flags != nullptr, DCQ_ERR_ARGUMENT, "bad arguments");
+  if (n == 0) return DCQ_OK;
+  DCQ_REQUIRE(x != nullptr && (reinterpret_cast<uintptr_t>(x) & 15u) == 0, DCQ_ERR_ARGUMENT,
+              "x must be 16-byte aligned");
+  int64_t blocks = (n / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(nonfinite_flags_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, n, flags);
+  DCQ_LAUNCH_CHECK("nonfinite_flags_kernel launch");
+  return DCQ_OK;
 }
 
 }  // extern "C"

@@ -304,6 +304,12 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
                          int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
                          int64_t ld_err, dcq_stream_t stream);
 
+/* *flags |= 1 when x[0 .. n) (float32, 16-byte aligned) holds a NaN, |= 2 when it holds an infinity; the caller zeroes
+ * *flags first and reads it after the stream has run.  One read of x.  Replaces the reference's
+ * `assert not t.isnan().any()` / `assert not t.isinf().any()` pairs on codes and inverse factors
+ * (quantizer/impl/base.py:250-251, quantizer/kernel/gptq.py:229-230, 272). */
+int dcq_nonfinite_flags(const float* x, int64_t n, int32_t* flags, dcq_stream_t stream);
+
 /* dst[r][c] = zero_columns[index[c]] ? 0 : src[r][index[c]] for row-major float32 matrices (leading dimensions ld_src,
  * ld_dst; `zero_columns` [C] bytes indexed by SOURCE column, or NULL; src != dst; 16-byte aligned pointers, leading
  * dimensions multiples of 4, C <= 36864).  Replaces the act-order gathers around the sweep, `W[:, perm]` with the dead

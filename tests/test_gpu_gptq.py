@@ -351,3 +351,26 @@ def test_gather_columns_equals_the_indexing_expression(rows, cols):
     inverse = torch.argsort(perm)
     assert torch.equal(engine.gather_columns(got, inverse), want[:, inverse])
     assert torch.equal(engine.gather_columns(src, inverse), src[:, inverse])
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1000003, 1 << 22])
+def test_assert_finite_names_what_it_found(n):
+    """The NaN / Inf assertions of the reference (impl/base.py:250-251, gptq.py:229-230) through the one-pass kernel:
+    silent on finite data, 'contains NaN.' / 'contains Inf.' in the reference's order otherwise."""
+    from deepcompressor_amd import engine
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g).cuda()
+    engine.assert_finite(x, "Quantized tensor")
+    for pos in sorted({0, n // 2, n - 1}):
+        for bad, name in ((float("nan"), "NaN"), (float("inf"), "Inf"), (float("-inf"), "Inf")):
+            y = x.clone()
+            y[pos] = bad
+            with pytest.raises(AssertionError, match=f"Quantized tensor contains {name}."):
+                engine.assert_finite(y, "Quantized tensor")
+    if n >= 3:
+        y = x.clone()
+        y[0], y[n - 1] = float("inf"), float("nan")
+        with pytest.raises(AssertionError, match="contains NaN."):
+            engine.assert_finite(y, "Quantized tensor")
+        with pytest.raises(AssertionError, match="contains Inf."):
+            engine.assert_finite(y, "Quantized tensor", inf_first=True)
