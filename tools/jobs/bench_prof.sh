@@ -6,5 +6,5 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/bp/prof -o b --
 python3 -c "
 import json
 d=json.loads(open('gpurun_out/bp/bench.json').read().strip().splitlines()[-1]); print('ms_per_step', d['ms_per_step'])"
-python3 tools/trace_timeline.py $(find gpurun_out/bp/prof -name "*.db" | head -1)
-python3 tools/prof_db.py $(find gpurun_out/bp/prof -name "*.db" | head -1) 14; find gpurun_out/bp -name "*.db" -delete
+python3 tools/trace_timeline.py $(find gpurun_out/bp/prof -name "*.db" | head -1) > gpurun_out/bp/timeline.txt
+python3 tools/prof_db.py $(find gpurun_out/bp/prof -name "*.db" | head -1) 70 > gpurun_out/bp/stats.txt; find gpurun_out/bp -name "*.db" -delete
