@@ -44,6 +44,25 @@ def test_hessian_matches_float64(T, C, dt):
     assert got[3, 3] == 0
 
 
+@pytest.mark.parametrize("T,C", [(16384, 4096), (8192, 2560), (4000, 1000)])
+@pytest.mark.parametrize("width", [8, 100, 224])
+def test_hessian_does_not_depend_on_the_round_width(T, C, width):
+    """dcq_hessian_round_width only changes how many workgroups are launched at a time (direct and transposed-copy
+    kernels, several K splits): the Hessian is the same bit for bit."""
+    from deepcompressor_amd._lib import lib
+    g = torch.Generator().manual_seed(T + C)
+    x = (torch.randn(T, C, generator=g) * torch.exp(torch.randn(C, generator=g))).to(torch.bfloat16).cuda()
+    base = torch.zeros(C, C, device="cuda")
+    hessian_accumulate(base, x, 2.0 / T)
+    lib().dcq_hessian_round_width(width)
+    try:
+        narrow = torch.zeros(C, C, device="cuda")
+        hessian_accumulate(narrow, x, 2.0 / T)
+    finally:
+        lib().dcq_hessian_round_width(0)
+    assert torch.equal(base, narrow)
+
+
 def test_hessian_float32_activations():
     g = torch.Generator().manual_seed(8)
     x = torch.randn(1001, 264, generator=g) * torch.exp(torch.randn(264, generator=g))
