@@ -191,22 +191,42 @@ __global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const S
     }
     float best_err = 0.0f;
     int best_k = 0;
-    for (int k = 0; k < p.K; ++k) {
-      const float r = p.ratios[k];
-      float cmax = bmax * r, cmin = 0.0f;
-      if (ZD != DCQ_ZERO_NONE) cmin = bmin * r;
-      if (ZD == DCQ_ZERO_PRE_SCALE) {
-        cmax = fmaxf(cmax, 0.0f);
-        cmin = fminf(cmin, 0.0f);
+    // The scale, zero point and reciprocal of a candidate are the same for the 8 lanes of a group: lane j works them
+    // out for candidate k0 + j, and the team then takes the candidates of the batch one by one from the lane that
+    // holds them (LDS-crossbar permute), instead of every lane repeating the ~40 instructions for every candidate.
+    const int team_first_lane4 = (lane & ~(kTeam - 1)) * 4;
+    for (int k0 = 0; k0 < p.K; k0 += kTeam) {
+      ScaleZero mine;
+      float mine_y = 0.0f;
+      int mine_ok = 0;
+      {
+        const int km = k0 + j < p.K ? k0 + j : p.K - 1;
+        const float r = p.ratios[km];
+        float cmax = bmax * r, cmin = 0.0f;
+        if (ZD != DCQ_ZERO_NONE) cmin = bmin * r;
+        if (ZD == DCQ_ZERO_PRE_SCALE) {
+          cmax = fmaxf(cmax, 0.0f);
+          cmin = fminf(cmin, 0.0f);
+        }
+        mine = scale_zero_from_range(st, cmax, cmin, cbs + 256, cbs + 512);
+        if (PACKED) {
+          mine_ok = mine.s >= 0x1p-60f && mine.s <= 0x1p60f && gabs + fabsf(mine.z) <= 0x1p60f;
+          mine_y = refined_rcp(mine.s);
+        }
       }
-      const ScaleZero sz = scale_zero_from_range(st, cmax, cmin, cbs + 256, cbs + 512);
+#pragma unroll 1
+    for (int k = k0; k < k0 + kTeam && k < p.K; ++k) {
+      const int from = team_first_lane4 + (k - k0) * 4;
+      ScaleZero sz;
+      sz.s = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mine.s)));
+      sz.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mine.z)));
       float pw[NPL];
       bool done = false;
       if (PACKED) {
-        const bool ok = sz.s >= 0x1p-60f && sz.s <= 0x1p60f && gabs + fabsf(sz.z) <= 0x1p60f;
+        const bool ok = __builtin_amdgcn_ds_bpermute(from, mine_ok) != 0;
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) {  // uniform over the wave
           done = true;
-          const float y = refined_rcp(sz.s);
+          const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mine_y)));
           const f32x2 z2 = {sz.z, sz.z}, s2 = {sz.s, sz.s};
 #pragma unroll
           for (int i = 0; i < NPL; i += 2) {
@@ -280,6 +300,7 @@ __global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const S
         best_err = err;
         best_k = k;
       }
+    }
     }
     if (j == kTeam - 1 && live) {
       const float r = p.ratios[best_k];
