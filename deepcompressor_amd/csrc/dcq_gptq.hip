@@ -796,17 +796,28 @@ __global__ __launch_bounds__(kSweepThreads, 4) void gptq_sweep_kernel(const Swee
 // scattered 4-byte read from global memory would move a whole cache line per element.
 constexpr int kGatherThreads = 256;
 
-__global__ __launch_bounds__(kGatherThreads) void gather_columns_kernel(const float* src, int64_t ld_src, int64_t R,
+template <int ST>
+__global__ __launch_bounds__(kGatherThreads) void gather_columns_kernel(const void* src_any, int64_t ld_src, int64_t R,
                                                                          int32_t C, const int64_t* index,
                                                                          const uint8_t* zero_columns, float* dst,
                                                                          int64_t ld_dst) {
+  using St = Storage<ST>;
+  using elem_t = typename St::elem_t;
   extern __shared__ __align__(16) unsigned char gather_smem[];
   float* row = reinterpret_cast<float*>(gather_smem);
+  const elem_t* src = static_cast<const elem_t*>(src_any);
   const int c4 = C & ~3;
   for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
-    const float* s = src + r * ld_src;
+    const elem_t* s = src + r * ld_src;
     for (int c = threadIdx.x * 4; c < c4; c += kGatherThreads * 4) {
-      float4 v = *reinterpret_cast<const float4*>(s + c);
+      float4 v;
+      if constexpr (ST == DCQ_F32) {
+        v = *reinterpret_cast<const float4*>(s + c);
+      } else {  // four 16-bit values, widened on the way in
+        const uint2 raw = *reinterpret_cast<const uint2*>(s + c);
+        v = make_float4(St::load(static_cast<uint16_t>(raw.x & 0xffffu)), St::load(static_cast<uint16_t>(raw.x >> 16)),
+                        St::load(static_cast<uint16_t>(raw.y & 0xffffu)), St::load(static_cast<uint16_t>(raw.y >> 16)));
+      }
       if (zero_columns) {
         const uchar4 z = *reinterpret_cast<const uchar4*>(zero_columns + c);
         if (z.x) v.x = 0.0f;
@@ -816,7 +827,8 @@ __global__ __launch_bounds__(kGatherThreads) void gather_columns_kernel(const fl
       }
       *reinterpret_cast<float4*>(row + c) = v;
     }
-    for (int c = c4 + threadIdx.x; c < C; c += kGatherThreads) row[c] = zero_columns && zero_columns[c] ? 0.0f : s[c];
+    for (int c = c4 + threadIdx.x; c < C; c += kGatherThreads)
+      row[c] = zero_columns && zero_columns[c] ? 0.0f : St::load(s[c]);
     __syncthreads();
     float* d = dst + r * ld_dst;
     for (int c = threadIdx.x * 4; c < c4; c += kGatherThreads * 4) {
@@ -942,20 +954,23 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
   return DCQ_OK;
 }
 
-int dcq_gather_columns(const float* src, int64_t ld_src, int64_t R, int64_t C, const int64_t* index,
+int dcq_gather_columns(const void* src, int32_t storage, int64_t ld_src, int64_t R, int64_t C, const int64_t* index,
                        const uint8_t* zero_columns, float* dst, int64_t ld_dst, dcq_stream_t stream) {
   DCQ_REQUIRE(R >= 0 && C > 0 && ld_src >= C && ld_dst >= C, DCQ_ERR_ARGUMENT, "bad sizes");
+  DCQ_REQUIRE(storage == DCQ_F32 || storage == DCQ_F16 || storage == DCQ_BF16, DCQ_ERR_ARGUMENT, "bad storage type");
   if (R == 0) return DCQ_OK;
   DCQ_REQUIRE(src && index && dst, DCQ_ERR_ARGUMENT, "NULL buffer");
-  DCQ_REQUIRE(src != dst, DCQ_ERR_ARGUMENT, "the gather is not done in place");
+  DCQ_REQUIRE(src != static_cast<const void*>(dst), DCQ_ERR_ARGUMENT, "the gather is not done in place");
   DCQ_REQUIRE(C <= 36864, DCQ_ERR_UNSUPPORTED, "rows of more than 36864 columns do not fit the LDS staging");
   DCQ_REQUIRE(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) |
                 reinterpret_cast<uintptr_t>(index)) & 15u) == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 &&
                   (zero_columns == nullptr || (reinterpret_cast<uintptr_t>(zero_columns) & 3u) == 0),
               DCQ_ERR_ARGUMENT, "src, dst, index must be 16-byte aligned with leading dimensions that are multiples of 4");
   const size_t lds = static_cast<size_t>((C + 3) / 4 * 4) * sizeof(float);
+  auto kern = storage == DCQ_F32 ? gather_columns_kernel<DCQ_F32>
+                                 : (storage == DCQ_F16 ? gather_columns_kernel<DCQ_F16> : gather_columns_kernel<DCQ_BF16>);
   if (lds > 64 * 1024) {
-    int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(gather_columns_kernel),
+    int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)),
                        "hipFuncSetAttribute(gather LDS)");
     if (rc != DCQ_OK) return rc;
@@ -963,7 +978,7 @@ int dcq_gather_columns(const float* src, int64_t ld_src, int64_t R, int64_t C, c
   const int64_t per_cu = lds > 0 ? (160 * 1024) / static_cast<int64_t>(lds) : 1;
   int64_t blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
   if (blocks > R) blocks = R;
-  hipLaunchKernelGGL(gather_columns_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kGatherThreads), lds,
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kGatherThreads), lds,
                      static_cast<hipStream_t>(stream), src, ld_src, R, static_cast<int32_t>(C), index, zero_columns, dst,
                      ld_dst);
   DCQ_LAUNCH_CHECK("gather_columns_kernel launch");

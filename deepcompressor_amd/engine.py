@@ -293,22 +293,24 @@ def assert_finite(values: torch.Tensor, what: str, *, inf_first: bool = False) -
 
 
 def gather_columns(src: torch.Tensor, index: torch.Tensor, zero_columns: torch.Tensor | None = None) -> torch.Tensor:
-    """``torch.where(zero_columns, 0, src)[:, index]`` for a float32 matrix (``zero_columns``: bool per source column),
-    one pass with each row staged in LDS; shapes the kernel does not take (rows that are not a multiple of 4 long or
-    longer than 36864) go through the torch expression."""
+    """``torch.where(zero_columns, 0, src.float())[:, index]`` for a float32 / float16 / bfloat16 matrix
+    (``zero_columns``: bool per source column) as a float32 matrix, one pass with each row staged in LDS; shapes the
+    kernel does not take (rows that are not a multiple of 4 long or longer than 36864) go through the torch
+    expression."""
     _require_gpu(src)
-    assert src.ndim == 2 and src.dtype == torch.float32 and index.dtype == torch.int64 and index.numel() == src.shape[1]
+    assert src.ndim == 2 and src.dtype in _TORCH_ROUND and index.dtype == torch.int64 and index.numel() == src.shape[1]
     R, Cn = src.shape
     src = src.contiguous()
     if Cn % 4 or Cn > 36864 or src.data_ptr() % 16:
+        src = src.to(torch.float32)
         if zero_columns is not None:
             src = torch.where(zero_columns, torch.zeros((), device=src.device, dtype=src.dtype), src)
         return src[:, index].contiguous()
     index = index.contiguous()
     mask = None if zero_columns is None else zero_columns.contiguous().view(torch.uint8)
-    out = torch.empty_like(src)
-    check(lib().dcq_gather_columns(ptr(src), Cn, R, Cn, ptr(index), ptr(mask), ptr(out), Cn, stream_of(src.device)),
-          "dcq_gather_columns")
+    out = torch.empty((R, Cn), dtype=torch.float32, device=src.device)
+    check(lib().dcq_gather_columns(ptr(src), storage_of(src.dtype), Cn, R, Cn, ptr(index), ptr(mask), ptr(out), Cn,
+                                   stream_of(src.device)), "dcq_gather_columns")
     return out
 
 

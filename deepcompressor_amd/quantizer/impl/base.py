@@ -312,6 +312,8 @@ class QuantizerImpl:
             # caller-supplied kernel object: it receives the float32 working tensor of the last step
             if outer is not None:
                 develop = restore(engine.prescale_groups(x2d, outer, lo, hi))
+            elif type(kernel) is QuantGptqKernel:
+                develop = tensor  # that kernel widens and permutes the weight in one pass and leaves its input alone
             else:
                 develop = tensor.to(torch.float32) if dtype != torch.float32 else tensor.clone()
             rd = None

@@ -359,7 +359,8 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
                   zero_domain: ZeroPointDomain | None, scale: torch.Tensor, zero: torch.Tensor,
                   gptq_config: QuantGptqConfig, inputs: TensorCache, quant_range: QuantRange | None = None,
                   range_bound: RangeBound | None = None, hessian: torch.Tensor | None = None) -> torch.Tensor:
-    """Quantized values of ``tensor`` (float32 working copy, modified) in the shape ``view_shape``.
+    """Quantized values of ``tensor`` (float32, float16 or bfloat16; left untouched: the float32 working copy is made
+    by the act-order gather) in the shape ``view_shape``.
 
     ``hessian`` (optional, not in the reference signature) lets callers that quantize several weights fed by the
     same activations (q/k/v, gate/up) pass one precomputed 2/n * X^T X instead of recomputing it per weight.
@@ -373,7 +374,7 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     R, Cn = n_rg * rg_size, n_cg * cg_size
     dev = tensor.device
     W = view.reshape(R, Cn)
-    assert W.dtype == torch.float32, "the working tensor must be float32"
+    assert W.dtype in (torch.float32, torch.float16, torch.bfloat16), "the weight must be float32 / float16 / bfloat16"
     # ---- Hessian (shared, never modified), dead channels, act-order permutation, damping, inverse factor
     hessian = hessian_of(inputs, dev) if hessian is None else hessian
     assert hessian.shape == (Cn, Cn), "activation channels do not match the weight's input channels"
@@ -403,7 +404,7 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     while True:
         dead, perm, inverse_perm, U, info = _inverse_factor_of(hessian, gptq_config, attempt)
         Wp = engine.gather_columns(W, perm, zero_columns=dead)  # dead channels zeroed, act-order (gptq.py:199-208)
-        Q = torch.zeros_like(Wp)
+        Q = torch.empty_like(Wp)  # the sweep writes every row and column
         check(lib().dcq_gptq_sweep(C.byref(step), ptr(Wp), Cn, R, Cn, ptr(U), ptr(s2), ptr(z2), z_scalar, rg_size,
                                    cg_size, n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, stream_of(dev)),
               "dcq_gptq_sweep")

@@ -310,12 +310,13 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
  * (quantizer/impl/base.py:250-251, quantizer/kernel/gptq.py:229-230, 272). */
 int dcq_nonfinite_flags(const float* x, int64_t n, int32_t* flags, dcq_stream_t stream);
 
-/* dst[r][c] = zero_columns[index[c]] ? 0 : src[r][index[c]] for row-major float32 matrices (leading dimensions ld_src,
- * ld_dst; `zero_columns` [C] bytes indexed by SOURCE column, or NULL; src != dst; 16-byte aligned pointers, leading
+/* dst[r][c] = zero_columns[index[c]] ? 0 : float(src[r][index[c]]) for a row-major source of `storage` type (DCQ_F32 /
+ * DCQ_F16 / DCQ_BF16) and a row-major float32 destination (leading dimensions ld_src, ld_dst in elements;
+ * `zero_columns` [C] bytes indexed by SOURCE column, or NULL; src != dst; 16-byte aligned pointers, leading
  * dimensions multiples of 4, C <= 36864).  Replaces the act-order gathers around the sweep, `W[:, perm]` with the dead
  * channels' columns zeroed (gptq.py:199-208) and `Q[:, inverse_perm]` (gptq.py:273-275): each row is staged in LDS
  * and gathered there. */
-int dcq_gather_columns(const float* src, int64_t ld_src, int64_t R, int64_t C, const int64_t* index,
+int dcq_gather_columns(const void* src, int32_t storage, int64_t ld_src, int64_t R, int64_t C, const int64_t* index,
                        const uint8_t* zero_columns, float* dst, int64_t ld_dst, dcq_stream_t stream);
 
 int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64_t C, const float* U,

@@ -370,6 +370,11 @@ def test_gather_columns_equals_the_indexing_expression(rows, cols):
     inverse = torch.argsort(perm)
     assert torch.equal(engine.gather_columns(got, inverse), want[:, inverse])
     assert torch.equal(engine.gather_columns(src, inverse), src[:, inverse])
+    for dt in (torch.bfloat16, torch.float16):  # 16-bit sources are widened on the way
+        narrow = src.to(dt)
+        want16 = torch.where(dead, torch.zeros((), device="cuda"), narrow.float())[:, perm]
+        got16 = engine.gather_columns(narrow, perm, zero_columns=dead)
+        assert got16.dtype == torch.float32 and torch.equal(got16, want16)
 
 
 @pytest.mark.parametrize("n", [1, 3, 4, 1000003, 1 << 22])
