@@ -729,6 +729,26 @@ __global__ __launch_bounds__(256) void flip_pad_rows_kernel(const float* src, in
     return;
   }
   const float* row = src + perm[n - 1 - i] * n;
+  if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (reinterpret_cast<uintptr_t>(perm) & 15u) == 0) {
+    // 16-byte loads and stores; the four indices of destination columns j .. j + 3 are perm[n-4-j .. n-1-j], reversed
+    for (int64_t j = threadIdx.x * 4; j < n; j += 256 * 4)
+      *reinterpret_cast<float4*>(flip_row + j) = *reinterpret_cast<const float4*>(row + j);
+    __syncthreads();
+    for (int64_t j = threadIdx.x * 4; j < np; j += 256 * 4) {
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (j < n) {
+        const longlong2 lo = *reinterpret_cast<const longlong2*>(perm + (n - 4 - j));
+        const longlong2 hi = *reinterpret_cast<const longlong2*>(perm + (n - 2 - j));
+        v = make_float4(flip_row[hi.y], flip_row[hi.x], flip_row[lo.y], flip_row[lo.x]);
+        if (i >= j && i < j + 4) {
+          float* d = i == j ? &v.x : (i == j + 1 ? &v.y : (i == j + 2 ? &v.z : &v.w));
+          *d = (*d == 0.0f ? 1.0f : *d) + diag_add;
+        }
+      }
+      *reinterpret_cast<float4*>(out + j) = v;
+    }
+    return;
+  }
   for (int64_t j = threadIdx.x; j < n; j += 256) flip_row[j] = row[j];
   __syncthreads();
   for (int64_t j = threadIdx.x; j < np; j += 256) {
