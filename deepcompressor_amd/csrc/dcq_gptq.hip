@@ -404,6 +404,40 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkParams p) {
   const int r0 = (blockIdx.x % (kTile / kReduceRows)) * kReduceRows;
   const int2 t = p.tile_map[tile_idx];
   const int bi = t.x, bj = t.y;
+  // Off-diagonal tiles that lie wholly inside the matrix (all but the diagonal and the ragged edge): 16-byte reads and
+  // writes of H, and the mirrored strip (256 rows x 16 columns) goes through LDS so that every thread writes one
+  // row's 64 contiguous bytes instead of sixteen 4-byte words a whole row apart.  The same sums, bit for bit.
+  __shared__ __align__(16) float strip[kReduceRows][kTile];
+  if (bi != bj && (bi + 1) * kTile <= p.C && (bj + 1) * kTile <= p.C && (p.C & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(p.H) & 15u) == 0) {
+    for (int e = threadIdx.x; e < kReduceRows * (kTile / 4); e += 256) {
+      const int r = e / (kTile / 4), c = (e % (kTile / 4)) * 4;
+      float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int sp = 0; sp < p.splits; ++sp) {
+        const float4 v = *reinterpret_cast<const float4*>(
+            p.partial + (static_cast<int64_t>(sp) * p.num_tiles + tile_idx) * (kTile * kTile) + (r0 + r) * kTile + c);
+        s4.x = s4.x + v.x;
+        s4.y = s4.y + v.y;
+        s4.z = s4.z + v.z;
+        s4.w = s4.w + v.w;
+      }
+      float4* h = reinterpret_cast<float4*>(p.H + static_cast<int64_t>(bi * kTile + r0 + r) * p.C + bj * kTile + c);
+      float4 sum = *h;
+      sum.x = sum.x + p.alpha * s4.x;
+      sum.y = sum.y + p.alpha * s4.y;
+      sum.z = sum.z + p.alpha * s4.z;
+      sum.w = sum.w + p.alpha * s4.w;
+      *h = sum;
+      *reinterpret_cast<float4*>(&strip[r][c]) = sum;
+    }
+    __syncthreads();
+    float* mirror = p.H + static_cast<int64_t>(bj * kTile + threadIdx.x) * p.C + bi * kTile + r0;
+#pragma unroll
+    for (int k = 0; k < kReduceRows; k += 4)
+      *reinterpret_cast<float4*>(mirror + k) = make_float4(strip[k][threadIdx.x], strip[k + 1][threadIdx.x],
+                                                           strip[k + 2][threadIdx.x], strip[k + 3][threadIdx.x]);
+    return;
+  }
   for (int e = threadIdx.x; e < kReduceRows * (kTile / 4); e += 256) {
     const int r = r0 + e / (kTile / 4), c = (e % (kTile / 4)) * 4;
     const int row = bi * kTile + r, col = bj * kTile + c;
