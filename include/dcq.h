@@ -332,7 +332,7 @@ int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64
  * multiple of 32; 16-byte aligned A, B with lda, ldb multiples of 4 take the fast load path.  Replaces the lazy update
  * `W[:, c_end:] -= Err @ U[c0:c_end, c_end:]` (gptq.py:269) and is the building block of the routine below.
  * Accuracy is that of a float32 GEMM for every size (error within a few 2^-24 of sum |a||b| per element); products of
- * 512 or more 128 x 128 tiles are computed on the bf16 matrix pipe from exact three-term bfloat16 splits of the
+ * 128 or more 128 x 128 tiles are computed on the bf16 matrix pipe from exact three-term bfloat16 splits of the
  * operands, so their low bits differ from those of a float32 multiply-accumulate chain.
  *
  * dcq_cholesky_inverse_upper: U[n][n] (upper triangular, row-major) with U^T U = S^-1 where
