@@ -2,7 +2,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2j
+O=gpurun_out/r2k
 mkdir -p $O
 if [ -z "$SKIP_TESTS" ]; then
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $O/tests.log 2>&1 || { tail -20 $O/tests.log; exit 1; }
@@ -22,7 +22,7 @@ timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/syrk_write -o w -- python3 
 python3 tools/kernel_pmc.py $O/syrk_pmc.json "syrk_kernel" $(find $O/syrk_fetch $O/syrk_write -name "*.db") > /dev/null
 python3 - <<'PY'
 import json
-d = json.load(open("gpurun_out/r2j/syrk_pmc.json"))
+d = json.load(open("gpurun_out/r2k/syrk_pmc.json"))
 k = d["kernels"]["syrk_kernel"]
 hessians = 8  # bench.py --steps 1 --warmup 0: the step's 4 and the 4 of the pass with nothing else on the chip
 out = {"kernel": "syrk_kernel: all rounds (kernel launches) of one dcq_hessian_accumulate call together; C = 14336 once "
@@ -30,8 +30,8 @@ out = {"kernel": "syrk_kernel: all rounds (kernel launches) of one dcq_hessian_a
        "method": d["method"], "kernel_launches_per_pass": k["launches_per_pass"], "hessians_per_pass": hessians,
        "avg_per_kernel_launch": k["avg_per_launch"],
        "avg_hbm_bytes_per_launch": k["hbm_bytes"] * k["launches_per_pass"] / hessians}
-json.dump(out, open("gpurun_out/r2j/syrk_traffic.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r2k/syrk_traffic.json", "w"), indent=1)
 print(json.dumps(out)[:400])
 PY
 find $O -name "*.db" -delete
-echo r2j done
+echo r2k done
