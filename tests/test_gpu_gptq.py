@@ -398,3 +398,11 @@ def test_assert_finite_names_what_it_found(n):
             engine.assert_finite(y, "Quantized tensor")
         with pytest.raises(AssertionError, match="contains Inf."):
             engine.assert_finite(y, "Quantized tensor", inf_first=True)
+
+
+def test_gather_and_finite_check_on_empty_inputs():
+    from deepcompressor_amd import engine
+    empty = torch.empty(0, 256, device="cuda")
+    out = engine.gather_columns(empty, torch.randperm(256).cuda())
+    assert out.shape == (0, 256) and out.dtype == torch.float32
+    engine.assert_finite(torch.empty(0, device="cuda"), "Quantized tensor")
