@@ -6,7 +6,15 @@ against 128 x 2048 = 262,144 synthetic calibration tokens already resident in HB
   per linear: fused 101-candidate range-ratio search -> static ranges -> scales/zeros -> GPTQ sweep -> dequantize.
 Layers are independent, so N GPUs each run K layers (weak scaling, no data-path collective).
 
-    python bench.py [--gpus N --steps K --warmup W] [--tokens T] [--no-cpu-baseline]
+    python bench.py [--gpus N --steps K --warmup W] [--tokens T] [--shard layers|rows] [--no-cpu-baseline]
+
+``--gpus N`` with N > 1 and no RANK in the environment: this process is only a launcher.  Before anything touches the
+GPU it starts N fresh ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one GPU
+each, RCCL), relays rank 0's JSON line and exits non-zero if any rank fails.  Under ``python -m torch.distributed.run``
+(RANK set) the script is one of the ranks.  ``--shard layers`` (default): every rank quantizes whole layers of its own
+(weak scaling, no data-path collective).  ``--shard rows``: ONE layer per step for the whole job -- the calibration
+tokens are split over the ranks (partial Hessians all-reduced), every rank searches and sweeps its slab of output rows
+of each linear, the slabs are all-gathered (strong scaling).
 """
 
 from __future__ import annotations
@@ -20,7 +28,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+torch = None  # imported by main() in the ranks; the launcher never loads it
 
 LLAMA3_8B_LAYER = [  # (name, out_features, in_features, activation id)
     ("q_proj", 4096, 4096, "attn_in"), ("k_proj", 1024, 4096, "attn_in"), ("v_proj", 1024, 4096, "attn_in"),
@@ -30,8 +38,10 @@ LLAMA3_8B_LAYER = [  # (name, out_features, in_features, activation id)
 PARAMS_PER_LAYER = sum(r * c for _, r, c, _ in LLAMA3_8B_LAYER)
 
 
-def make_layer(device, tokens: int, seed: int):
-    """Synthetic bf16 weights and activations of one decoder layer (per-channel log-normal activation gains)."""
+def make_layer(device, tokens: int, seed: int, weight_seed: int | None = None):
+    """Synthetic bf16 weights and activations of one decoder layer (per-channel log-normal activation gains).
+    ``weight_seed``: draw the weights from a generator of their own (ranks that share one layer's weights but hold
+    different calibration tokens)."""
     from deepcompressor_amd.data.cache import TensorCache
     from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
 
@@ -48,6 +58,8 @@ def make_layer(device, tokens: int, seed: int):
         acts[key] = x
         caches[key] = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_cached=1, num_total=1,
                                   num_samples=tokens, orig_device=device)
+    if weight_seed is not None:
+        g = torch.Generator(device=device).manual_seed(weight_seed)
     weights = {name: (torch.randn((r, c), generator=g, device=device) * 0.02).to(torch.bfloat16)
                for name, r, c, _ in LLAMA3_8B_LAYER}
     return weights, caches
@@ -90,7 +102,7 @@ def stage_config():
         kernel_gptq=QuantGptqConfig(damp_percentage=0.01, block_size=128, num_inv_tries=250, hessian_block_size=512))
 
 
-def quantize_layer(weights, caches, config, syrk_events=None, streams: int = 1):
+def quantize_layer(weights, caches, config, syrk_events=None, streams: int = 1, world: int = 1, rank: int = 0):
     """The hot path for one layer through the weight stage of the package (the reference's
     app/llm/quant/weight.py:24-105): range search, then GPTQ fed by the cached inputs, for the 7 linears.  Returns the
     modules holding the dequantized weights (kept so nothing is optimised away)."""
@@ -116,7 +128,8 @@ def quantize_layer(weights, caches, config, syrk_events=None, streams: int = 1):
             _lib.lib().dcq_profile_next_hessian(e0.cuda_event, e1.cuda_event)
             syrk_events.append((e0, e1, channels))
 
-    quantize_layer_weights(entries, config, {}, layer_cache=layer_cache, streams=streams, hessian_hook=hessian_hook)
+    quantize_layer_weights(entries, config, {}, layer_cache=layer_cache, streams=streams, hessian_hook=hessian_hook,
+                           world=world, rank=rank)
     return [e.module for e in entries]
 
 
@@ -366,6 +379,68 @@ def cpu_baseline(tokens_sample: int = 8192):
     }
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch(n: int, argv: list, dry: bool) -> int:
+    """Start ``n`` ranks of this script, one per GPU, and relay rank 0's output.  Runs in a process that has not
+    loaded torch or touched the GPU; the ranks are fresh child processes (never an exec of an initialised one).
+    Returns the exit code: 0 only when every rank exited with 0."""
+    import subprocess
+
+    port = _free_port()
+    children = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        children.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__), *argv], env=env,
+                                         stdout=subprocess.PIPE if (r == 0 or dry) else sys.stderr, text=True))
+    failed = 0
+    if dry:
+        seen = []
+        for child in children:
+            text, _ = child.communicate()
+            failed = failed or child.returncode
+            seen.extend(json.loads(line) for line in text.splitlines() if line.startswith("{"))
+        print(json.dumps({"dry_launch": seen}))
+        return failed
+    import threading
+
+    def relay() -> None:
+        for line in children[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    pending = set(range(n))
+    while pending and not failed:
+        for r in sorted(pending):
+            code = children[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    failed = code
+                    print(f"bench.py: rank {r} exited with {code}", file=sys.stderr)
+        time.sleep(0.2)
+    if failed:  # a rank died: the others would wait in a collective for ever
+        for r in pending:
+            children[r].terminate()
+        for r in pending:
+            try:
+                children[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                children[r].kill()
+    pump.join(timeout=10)
+    return failed
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -376,32 +451,65 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip the stage rooflines and the other configs")
     ap.add_argument("--streams", type=int, default=4,
                     help="run the independent groups of linears of a layer concurrently on this many HIP streams")
+    ap.add_argument("--shard", choices=("layers", "rows"), default="layers",
+                    help="layers: every rank quantizes whole layers of its own (weak scaling); rows: one layer per "
+                         "step for the whole job, tokens and output rows split over the ranks (strong scaling)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the ranks (nccl = RCCL); gloo is "
+                                                      "for rehearsals with several ranks on one GPU")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks, have each report its environment and exit (no GPU work)")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and (args.gpus > 1 or args.dry_launch):
+        sys.exit(launch(args.gpus, sys.argv[1:], args.dry_launch))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_launch:
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world_size": world, "pid": os.getpid(),
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}))
+        return
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size counts", file=sys.stderr)
+    global torch
+    import torch
+
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
+        index = local_rank % max(1, torch.cuda.device_count()) if args.backend != "nccl" else local_rank
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", index))
+        else:
+            dist.init_process_group(backend=args.backend)
+        world = dist.get_world_size()  # what the communicator saw, reported as n_gpus
+    else:
+        index = local_rank
+    device = torch.device("cuda", index)
     torch.cuda.set_device(device)
 
     from deepcompressor_amd.parallel import barrier_and_max
 
+    rows_mode = args.shard == "rows" and world > 1
     objs = build_objects()
     config = stage_config()
-    weights, caches = make_layer(device, args.tokens, seed=1234 + rank)
+    if rows_mode:
+        # one layer for the whole job: the same weights on every rank, an equal share of the tokens each
+        assert args.tokens % world == 0, "--shard rows: the token count must divide by the number of ranks"
+        my_tokens, split = args.tokens // world, dict(world=world, rank=rank)
+        weights, caches = make_layer(device, my_tokens, seed=1234 + rank, weight_seed=4321)
+    else:
+        my_tokens, split = args.tokens, {}
+        weights, caches = make_layer(device, args.tokens, seed=1234 + rank)
     for _ in range(args.warmup):
-        quantize_layer(weights, caches, config, streams=args.streams)
+        quantize_layer(weights, caches, config, streams=args.streams, **split)
     torch.cuda.synchronize()
     barrier_and_max(0.0, world, device)
     syrk_events: list = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        outputs = quantize_layer(weights, caches, config, syrk_events, streams=args.streams)
+        outputs = quantize_layer(weights, caches, config, syrk_events, streams=args.streams, **split)
     torch.cuda.synchronize()
     elapsed = barrier_and_max(time.perf_counter() - t0, world, device)
     del outputs
@@ -426,38 +534,41 @@ def main() -> None:
         gptq_mod.clear_hessian_cache()
 
     if rank == 0:
-        total_params = PARAMS_PER_LAYER * args.steps * world
+        total_params = PARAMS_PER_LAYER * args.steps * (1 if rows_mode else world)
         # dominant kernel: the MFMA SYRK.  Algorithmic work of one launch = 2 * T * C^2 flop (X^T X as the reference
         # computes it); the kernel executes the upper-triangular tiles only.
         syrk_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in syrk_events)
-        syrk_flop = sum(2.0 * args.tokens * c * c for _, _, c in syrk_events)
+        syrk_flop = sum(2.0 * my_tokens * c * c for _, _, c in syrk_events)
         tiles = lambda c: (-(-c // 256)) * (-(-c // 256) + 1) // 2  # noqa: E731
-        exec_flop = sum(2.0 * args.tokens * tiles(c) * 256 * 256 for _, _, c in syrk_events)
+        exec_flop = sum(2.0 * my_tokens * tiles(c) * 256 * 256 for _, _, c in syrk_events)
         algorithmic = syrk_flop / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
         executed = exec_flop / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
         # HBM-side bytes per launch of that kernel, from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, see the
         # file for the method); only valid for the contract workload it was measured on
         traffic = None
         tpath = SYRK_PMC_FILE if os.path.exists(SYRK_PMC_FILE) else os.path.join(ROOT, "profiles", "r1_syrk_traffic.json")
-        if args.tokens == 128 * 2048 and os.path.exists(tpath):
+        if my_tokens == 128 * 2048 and os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f)["avg_hbm_bytes_per_launch"]
         alone_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in alone_events)
-        alone_exec = sum(2.0 * args.tokens * tiles(c) * 256 * 256 for _, _, c in alone_events)
+        alone_exec = sum(2.0 * my_tokens * tiles(c) * 256 * 256 for _, _, c in alone_events)
         alone = alone_exec / (alone_ms * 1e-3) / 1e12 if alone_ms > 0 else 0.0
         n_launch = max(1, len(syrk_events))
         # algorithmic bytes of a launch: X read once (2 T C) and H written once (4 C^2)
-        syrk_bytes = sum(2.0 * args.tokens * c + 4.0 * c * c for _, _, c in syrk_events) / n_launch
+        syrk_bytes = sum(2.0 * my_tokens * c + 4.0 * c * c for _, _, c in syrk_events) / n_launch
         line = {
             "metric": "quantized params/sec (whole node), Llama-3-8B GPTQ W4 g128 + range search",
             "value": total_params / elapsed, "unit": "params/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if rows_mode else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "GPTQ W4A16 g128 (uint4 PostScale, fp16 scales) + 101-ratio range search on the 7 "
                                    "linears of one Llama-3-8B decoder layer per step, bf16 weights/activations, "
                                    f"{args.tokens} calibration tokens resident in HBM",
                        "params_per_step": PARAMS_PER_LAYER, "tokens": args.tokens,
-                       "parallelism": f"independent layers x{world}", "streams_per_gpu": args.streams},
+                       "parallelism": (f"one layer over {world} ranks: tokens split (Hessians all-reduced), output "
+                                       f"rows split (slabs all-gathered)" if rows_mode else
+                                       f"independent layers x{world}"),
+                       "backend": args.backend if world > 1 else None, "streams_per_gpu": args.streams},
             # frac = matrix-core utilisation: the flops the kernel EXECUTES (upper-triangular 256-tiles only, about
             # half of 2 T C^2) over the dense bf16 peak; the algorithmic figure (2 T C^2 credited per launch) beside it
             "roofline": {"bound": "mfma", "achieved": executed, "peak": 2500.0, "unit": "TFLOP/s",

@@ -175,8 +175,8 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
                            quantizer_state_dict: dict[str, tp.Any],
                            layer_cache: dict[str, IOTensorsCache] | None = None,
                            return_with_scale_state_dict: bool = False, develop_dtype: torch.dtype = torch.float32,
-                           streams: int = 1, hessian_hook: tp.Callable[[int], None] | None = None
-                           ) -> dict[str, torch.Tensor | float | None]:
+                           streams: int = 1, hessian_hook: tp.Callable[[int], None] | None = None,
+                           world: int = 1, rank: int = 0) -> dict[str, torch.Tensor | float | None]:
     """app/llm/quant/weight.py:24-105.  Pass 1 calibrates the range of every linear that has no entry in
     ``quantizer_state_dict`` yet (and stores it there); pass 2 reloads each range, quantizes the weight with the
     configured kernel (GPTQ when set, fed by the linear's cached inputs) and writes the dequantized weight back into
@@ -186,10 +186,21 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
     the cached inputs they share (q/k/v, gate/up ...); the groups' Hessians are computed one after the other on the
     caller's stream, each with the whole chip, largest pipeline first, and every group's searches, inverse factor and
     sweeps start on a stream of their own as soon as that group's Hessian is there.  ``hessian_hook(channels)`` is
-    called right before each of those Hessians is enqueued (a measurement hook)."""
+    called right before each of those Hessians is enqueued (a measurement hook).
+
+    ``world`` > 1 (no counterpart in the reference either): ONE layer split over the ``world`` processes of the default
+    process group, one per GPU.  Every rank passes the same modules (full weights) and the cache of ITS share of the
+    calibration tokens: the partial Hessians are all-reduced, every rank searches and quantizes rows
+    ``row_shard(out_features, world, rank)`` of each linear (search per group, scales and the GPTQ sweep are
+    independent per output row given the Hessian), and the dequantized slabs are all-gathered into every rank's
+    modules.  ``quantizer_state_dict`` and the returned scale entries describe the rank's own rows."""
     from ..quantizer.kernel.gptq import clear_hessian_cache
 
     layer_cache = layer_cache or {}
+    if world > 1:
+        return _quantize_layer_weights_row_sharded(entries, config, quantizer_state_dict, layer_cache,
+                                                   return_with_scale_state_dict, develop_dtype, streams, hessian_hook,
+                                                   world, rank)
     try:
         if streams > 1 and layer_cache and config.enabled_gptq and len(entries) > 1:
             return _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, layer_cache,
@@ -200,6 +211,60 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
         # the GPTQ kernel memoises the Hessian (and its inverse factor) of the last activation cache together with a
         # reference to that cache; a layer's caches must not outlive the layer
         clear_hessian_cache()
+
+
+def _row_multiple(config: LlmWeightQuantizerConfig) -> int:
+    """Rows that must stay together in a slab: the largest row extent of any quantization group (a group shape of
+    (1, g) cuts nowhere; whole-tensor or whole-column groups cannot be row-sharded)."""
+    multiple = 1
+    for shape in config.group_shapes:
+        if shape[0] <= 0:
+            raise ValueError("groups that span all output rows cannot be sharded by rows")
+        multiple = max(multiple, int(shape[0]))
+    return multiple
+
+
+def _quantize_layer_weights_row_sharded(entries, config, quantizer_state_dict, layer_cache,
+                                        return_with_scale_state_dict, develop_dtype, streams, hessian_hook, world, rank):
+    from ..parallel import all_gather_slabs, row_shard
+    from ..quantizer.kernel import gptq as gptq_mod
+
+    multiple = _row_multiple(config)
+    device = entries[0].module.weight.device
+    full = [e.module.weight.data for e in entries]
+    bounds = [[row_shard(w.shape[0], world, r, multiple) for r in range(world)] for w in full]
+    try:
+        if layer_cache and config.enabled_gptq:
+            # token-sharded Hessians, the same order on every rank (collectives must line up): largest first
+            seen, caches = set(), []
+            for e in sorted(entries, key=lambda e: -e.module.in_features):
+                cache = layer_cache[e.name].inputs.front()
+                key = gptq_mod.inputs_key(cache, device)
+                if key not in seen:
+                    seen.add(key)
+                    caches.append((e.module.in_features, cache))
+            for channels, cache in caches:
+                if hessian_hook is not None:
+                    hessian_hook(channels)
+                gptq_mod.prepare_hessians([cache], device, world=world)
+        for e, w, b in zip(entries, full, bounds):
+            begin, end = b[rank]
+            e.module.weight.data = w[begin:end]  # a contiguous view of whole rows
+        if streams > 1 and layer_cache and config.enabled_gptq and len(entries) > 1:
+            out = _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, layer_cache,
+                                                     return_with_scale_state_dict, develop_dtype, streams, None)
+        else:
+            out = _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache,
+                                          return_with_scale_state_dict, develop_dtype)
+        for e, w, b in zip(entries, full, bounds):
+            e.module.weight.data = all_gather_slabs(e.module.weight.data, [hi - lo for lo, hi in b], world, rank)
+        return out
+    except BaseException:
+        for e, w in zip(entries, full):
+            e.module.weight.data = w
+        raise
+    finally:
+        gptq_mod.clear_hessian_cache()
 
 
 def _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, layer_cache, return_with_scale_state_dict,

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import torch
 
-__all__ = ["assign_round_robin", "assign_by_cost", "barrier_and_max", "all_reduce_sum", "all_reduce_max", "row_shard", "map_rows_sharded",
+__all__ = ["assign_round_robin", "assign_by_cost", "barrier_and_max", "all_reduce_sum", "all_reduce_max", "row_shard", "map_rows_sharded", "all_gather_slabs",
            "search_range_row_sharded", "run_on_streams"]
 
 
@@ -104,9 +104,24 @@ def map_rows_sharded(fn, weight: torch.Tensor, world: int, rank: int, multiple: 
     begin, end = row_shard(weight.shape[0], world, rank, multiple)
     mine = fn(weight[begin:end]).contiguous()
     sizes = [row_shard(weight.shape[0], world, r, multiple) for r in range(world)]
-    parts = [torch.empty((e - b, *mine.shape[1:]), dtype=mine.dtype, device=mine.device) for b, e in sizes]
-    dist.all_gather(parts, mine) if len({e - b for b, e in sizes}) == 1 else _all_gather_ragged(parts, mine, rank, world)
-    return torch.cat(parts, dim=0)
+    return all_gather_slabs(mine, [e - b for b, e in sizes], world, rank)
+
+
+def all_gather_slabs(mine: torch.Tensor, rows: list[int], world: int, rank: int) -> torch.Tensor:
+    """Concatenation along dim 0 of every rank's slab (rank r contributes ``rows[r]`` rows; ``mine`` is this rank's).
+    The slabs travel in the memory the backend can move (device memory under RCCL, host memory under gloo) and the
+    result comes back on ``mine``'s device."""
+    if world <= 1:
+        return mine
+    dist = _dist()
+    home = _collective_device(dist)
+    sent = mine.contiguous() if mine.device.type == home.type else mine.to(home)
+    parts = [torch.empty((n, *sent.shape[1:]), dtype=sent.dtype, device=sent.device) for n in rows]
+    if len(set(rows)) == 1:
+        dist.all_gather(parts, sent)
+    else:
+        _all_gather_ragged(parts, sent, rank, world)
+    return torch.cat(parts, dim=0).to(mine.device)
 
 
 def search_range_row_sharded(weight: torch.Tensor, config, quantizer, world: int, rank: int, multiple: int = 1):

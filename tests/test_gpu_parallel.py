@@ -206,3 +206,81 @@ def test_token_sharded_smoothing_decides_like_the_unsharded_one():
         for r in range(world):  # abs-max spans reduce exactly; the winner of the search is the same
             np.testing.assert_array_equal(results[r][i][0], scale, err_msg=f"{strategy} rank {r}")
             np.testing.assert_array_equal(results[r][i][1], weight, err_msg=f"{strategy} rank {r}")
+
+
+def _stage(world: int, rank: int, gptq: bool):
+    """The weight stage on a toy layer (two linears fed by the same tokens, one by its own), 4 batches of tokens; with
+    two ranks each holds two of the batches and half of every linear's output rows."""
+    import torch.nn as nn
+
+    from deepcompressor_amd.app import LinearEntry, LlmWeightQuantizerConfig, quantize_layer_weights
+    from deepcompressor_amd.calib.config import (SearchBasedCalibGranularity, SearchBasedCalibObjective,
+                                                 SearchBasedCalibStrategy, SkipBasedDynamicRangeCalibConfig)
+    from deepcompressor_amd.data.cache import IOTensorsCache, TensorCache, TensorsCache
+    from deepcompressor_amd.data.dtype import QDType
+    from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
+    from deepcompressor_amd.data.zero import ZeroPointDomain
+    from deepcompressor_amd.quantizer import QuantGptqConfig
+
+    g = torch.Generator().manual_seed(5)
+    shapes = [("q_proj", 96, 256, "a"), ("k_proj", 40, 256, "a"), ("down_proj", 64, 384, "b")]
+    xs = {}
+    for key, c in (("a", 256), ("b", 384)):
+        gains = torch.exp(torch.randn(c, generator=g) * 0.7)
+        batches = [(torch.randn(1, 160, c, generator=g) * gains).to(torch.bfloat16).cuda() for _ in range(4)]
+        mine = batches[rank::world]
+        xs[key] = TensorCache(mine, channels_dim=-1, reshape=LinearReshapeFn(), num_cached=len(mine),
+                              num_total=len(mine), num_samples=len(mine), orig_device=torch.device("cuda"))
+    entries, layer_cache = [], {}
+    for name, r, c, key in shapes:
+        w = torch.randn(r, c, generator=g) * 0.03
+        w = torch.where(torch.rand(r, c, generator=g) < 0.01, w * 5, w).to(torch.bfloat16).cuda()
+        module = nn.Linear(c, r, bias=False, device="meta")
+        module.weight = nn.Parameter(w, requires_grad=False)
+        entries.append(LinearEntry(key=name, name=f"layer.{name}", module=module))
+        layer_cache[f"layer.{name}"] = IOTensorsCache(inputs=TensorsCache(xs[key]))
+    config = LlmWeightQuantizerConfig(
+        dtype=QDType.uint4, zero_point=ZeroPointDomain.PostScale, group_shapes=((1, 128),), scale_dtypes=(torch.float16,),
+        calib_range=SkipBasedDynamicRangeCalibConfig(
+            degree=2.4, objective=SearchBasedCalibObjective.TensorError, strategy=SearchBasedCalibStrategy.GridSearch,
+            granularity=SearchBasedCalibGranularity.Group, max_shrink=0.2, max_expand=1.0, num_grids=20),
+        kernel_gptq=QuantGptqConfig(damp_percentage=0.01, block_size=128, num_inv_tries=250) if gptq else None)
+    state: dict = {}
+    quantize_layer_weights(entries, config, state, layer_cache=layer_cache, streams=2 if gptq else 1, world=world,
+                           rank=rank)
+    return [e.module.weight.data.float().cpu().numpy() for e in entries]
+
+
+def _stage_worker(rank: int, world: int, port: int, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        out.put((rank, [_stage(world, rank, gptq) for gptq in (False, True)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_layer_stage_split_by_tokens_and_rows_equals_the_whole_stage():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stage_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(out.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i, gptq in enumerate((False, True)):
+        whole = _stage(1, 0, gptq)
+        for a, b, w in zip(results[0][i], results[1][i], whole):
+            np.testing.assert_array_equal(a, b)  # every rank ends with the same full weights
+            assert a.shape == w.shape
+            if gptq:  # the Hessian's float32 sums run in another order when the tokens are split
+                assert (a == w).mean() >= 0.99
+            else:  # search + round-to-nearest are independent per row: nothing may differ
+                np.testing.assert_array_equal(a, w)
