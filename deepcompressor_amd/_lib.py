@@ -56,16 +56,16 @@ class Step(C.Structure):
 _p, _i32, _i64, _f, _d = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 _SIGNATURES = {
     "dcq_round_to_codebook": [_p, _p, _i64, _i32, _p, _i32, _p],
-    "dcq_fake_quant_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _p, _i32, _f, _p, _p, _p, _p, _p],
-    "dcq_group_range": [_p, _i32, _i64, _i64, _i32, _p, _f, _f, _p, _p, _p],
+    "dcq_fake_quant_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _p, _i32, _f, _p, _p, _p, _p, _p, _p],
+    "dcq_group_range": [_p, _i32, _i64, _i64, _i32, _p, _f, _f, _p, _p, _p, _p],
     "dcq_range_to_scale": [C.POINTER(Step), _i64, _p, _p, _p, _i32, _f, _p, _p, _p, _p],
     "dcq_scale_level": [C.POINTER(Rounding), _p, _i64, _i64, _i32, _f, _p, _p],
     "dcq_round_values": [C.POINTER(Rounding), _p, _p, _i64, _p],
-    "dcq_selftest_division": [_p, _p, _p, _p, _p, _i64, _p],
+    "dcq_selftest_division": [_p, _p, _p, _p, _p, _p, _i64, _p],
     "dcq_scale_join": [_p, _p, _i64, _i64, _i32, _p, _p],
     "dcq_zero_point": [C.POINTER(Step), _i64, _p, _p, _p, _p],
     "dcq_quantize_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _p, _p, _f, _f, _i32, _f, _f, _p, _i32, _p, _p,
-                            _p],
+                            _p, _p],
     "dcq_prescale_groups": [_p, _i32, _i64, _i64, _p, _f, _f, _p, _p],
     "dcq_dequantize_groups": [C.POINTER(Step), _p, _i64, _i64, _p, _p, _p, _i32, _f, _f, _p, _i32, _p],
     "dcq_pow_table": [_i32, _d, _p, _p],
@@ -82,13 +82,13 @@ _SIGNATURES = {
     "dcq_cholesky_inverse_upper_static": [_p, _i64, _p, _f, _p, _p, _p],
     "dcq_gemm_f64": [_p, _i32, _i64, _i32, _i64, _p, _i32, _i64, _i64, _p, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "dcq_fake_quant_groups_outer": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _f, _f, _i32, _f, _f, _p, _p, _i32, _f, _p,
-                                    _i32, _p, _p, _p, _p],
+                                    _i32, _p, _p, _p, _p, _p],
     "dcq_fake_quant_progressive": [C.POINTER(Step), C.POINTER(Step), _p, _i32, _i64, _i64, _i64, _i32, _f, _i32, _f, _f, _f,
-                                   _i32, _f, _f, _p, _p, _p, _p, _p, _p],
+                                   _i32, _f, _f, _p, _p, _p, _p, _p, _p, _p],
     "dcq_fake_quant_groups_two_level": [C.POINTER(Step), C.POINTER(Rounding), _f, _p, _i32, _i64, _i64, _i32, _f, _p, _p,
-                                        _p, _p, _p, _p, _p],
+                                        _p, _p, _p, _p, _p, _p],
     "dcq_smooth_fake_quant_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _i64, _p, _i32, _i32, _i32, _f, _p, _p, _d,
-                                     _p, _p],
+                                     _p, _p, _p],
     "dcq_channel_metric": [_p, _i32, _i64, _i64, _i64, _i32, _p, _p, _p],
     "dcq_scale_channels": [_p, _i32, _i64, _i64, _i64, _p, _i64, _i32, _p, _i32, _p],
     "dcq_range_search_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _i32, _d, _p, _p, _p, _p, _p, _p, _i32,

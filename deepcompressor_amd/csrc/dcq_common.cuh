@@ -33,7 +33,7 @@ struct OuterStep {
 // lean fused kernel (dcq_fused.hip); DCQ_ERR_UNSUPPORTED means "use the general kernel"
 int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t G, int64_t S, const float* range_max,
                          const float* range_min, int has_ratio, float ratio, void* dequant, float* codes, float* scale,
-                         float* zero, hipStream_t stream, const OuterStep* outer = nullptr);
+                         float* zero, hipStream_t stream, const OuterStep* outer = nullptr, int32_t* nonfinite = nullptr);
 
 // lean kernel for value-table (floating-point) dtypes without zero point, one or two scale levels (dcq_fused.hip)
 // float32 GEMM (dcq_gemm_f32) with the arithmetic path chosen by the caller: the float32 matrix instructions, or
@@ -45,7 +45,7 @@ int gemm_f32_on_path(const float* A, int64_t lda, int32_t a_kmajor, const float*
 int try_launch_fused_table(const dcq_step& st, const void* x, int storage, int64_t G, int64_t S, int has_ratio,
                            float ratio, const float* tensor_absmax, const dcq_rounding* level0, float level0_span,
                            void* dequant, float* codes, float* level0_out, float* level1_out, float* scale,
-                           float* zero, hipStream_t stream);
+                           float* zero, hipStream_t stream, int32_t* nonfinite = nullptr);
 
 // float -> storage dtype -> double of a power's exponent: torch rounds the scalar exponent of Tensor.pow_ to the tensor's
 // dtype (dcq_search.hip)
@@ -243,6 +243,32 @@ __device__ __forceinline__ f32x2 div_fast2(f32x2 x, const Divisor& d) {
   q = __builtin_elementwise_fma(r, y, q);
   r = __builtin_elementwise_fma(ns, q, x);
   return __builtin_elementwise_fma(r, y, q);
+}
+
+// The same quotient with ONE correction step, for a divisor whose significand has at most 16 bits (a scale rounded
+// to float16 / bfloat16, an integer scale of up to 8 bits, a product of a float8 and a 16-bit scale) and any float32
+// x, inside the same guard.  Why one step is enough then: with y within one ulp of 1 / s, q = RN(x y) is within
+// 2^-22.4 |x / s|; r = x - s q is a multiple of ulp16(s) ulp(q) below 2^18 such units, so the fused multiply-add
+// delivers it exactly; q + r y differs from the exact quotient by |r / s| 2^-23 < 2^-45 |x / s|; and the exact
+// quotient of a 24-bit by a 16-bit significand stays at least 2^-41 |x / s| away from every midpoint between two
+// float32 values (x - s m is a non-zero multiple of ulp16(s) ulp25(m) for a 25-bit midpoint m: s m has an odd
+// significand of more than 24 bits and cannot equal x), so rounding q + r y rounds the exact quotient.
+__device__ __forceinline__ f32x2 div_short2(f32x2 x, const Divisor& d) {
+  const f32x2 y = {d.y, d.y}, ns = {-d.s, -d.s};
+  const f32x2 q = x * y;
+  const f32x2 r = __builtin_elementwise_fma(ns, q, x);
+  return __builtin_elementwise_fma(r, y, q);
+}
+
+__device__ __forceinline__ float div_short(float x, const Divisor& d) {
+  const float q = x * d.y;
+  const float r = __builtin_fmaf(-d.s, q, x);
+  return __builtin_fmaf(r, d.y, q);
+}
+
+// whether a scale rounded by `kind` (a dcq_rounding kind) has a significand of at most 16 bits
+__host__ __device__ constexpr bool short_significand(int kind) {
+  return kind == DCQ_ROUND_F16 || kind == DCQ_ROUND_BF16 || kind == DCQ_ROUND_INT;
 }
 
 __device__ __forceinline__ float div_fast(float x, const Divisor& d) {

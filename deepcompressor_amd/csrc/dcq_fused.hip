@@ -40,7 +40,59 @@ struct FusedParams {
   float outer_lo, outer_hi;
   int32_t deq_clamp;
   float deq_lo, deq_hi;
+  // |= kNonfiniteSeen when an element of x is NaN or +-Inf (NULL: not wanted)
+  int32_t* nonfinite;
+  // streaming (non-temporal) loads and stores: for tensors that do not fit the on-die caches anyway
+  int32_t stream_hint;
 };
+
+// Tensors whose reads plus writes exceed this many bytes are moved with non-temporal loads and stores (measured on a
+// 1.07 GB bf16 tensor, uint4 groups of 128: 186 -> 171 us; below the 256 MiB Infinity Cache a repeated pass is served
+// on-die and the hint would throw that away).
+constexpr int64_t kStreamBytes = int64_t{192} << 20;
+constexpr int32_t kNonfiniteSeen = 4;
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_piece(const uint4* p, bool nt) {
+  if (nt) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *p;
+}
+__device__ __forceinline__ float4 load_piece(const float4* p, bool nt) {
+  if (nt) {
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *p;
+}
+__device__ __forceinline__ void store_piece(uint4* p, const uint4& r, bool nt) {
+  if (nt) {
+    const u32x4_t v = {r.x, r.y, r.z, r.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p));
+  } else {
+    *p = r;
+  }
+}
+__device__ __forceinline__ void store_piece(float4* p, const float4& r, bool nt) {
+  if (nt) {
+    const f32x4_t v = {r.x, r.y, r.z, r.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(p));
+  } else {
+    *p = r;
+  }
+}
+
+// NaN / Inf detection that rides on the read: acc += x * 0 over every element is NaN as soon as one x is NaN or
+// +-Inf (Inf * 0 = NaN) and stays 0 otherwise.  For the 16-bit types the two-element dot product instructions take
+// the packed words as they are loaded: one instruction per two elements.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void report_nonfinite(float acc, int32_t* flags) {
+  if (flags != nullptr && acc != acc) atomicOr(flags, kNonfiniteSeen);
+}
 
 __device__ __forceinline__ uint16_t bf16_rne_hw(float x) {
   const __bf16 h = static_cast<__bf16>(x);
@@ -57,6 +109,12 @@ struct Elem<DCQ_F32> {
     v[0] = r.x, v[1] = r.y, v[2] = r.z, v[3] = r.w;
   }
   static __device__ __forceinline__ raw_t pack(const float* v) { return make_float4(v[0], v[1], v[2], v[3]); }
+  static __device__ __forceinline__ float probe(const raw_t& r, float acc) {
+    acc = __builtin_fmaf(r.x, 0.0f, acc);
+    acc = __builtin_fmaf(r.y, 0.0f, acc);
+    acc = __builtin_fmaf(r.z, 0.0f, acc);
+    return __builtin_fmaf(r.w, 0.0f, acc);
+  }
 };
 template <>
 struct Elem<DCQ_BF16> {
@@ -71,11 +129,21 @@ struct Elem<DCQ_BF16> {
     }
   }
   static __device__ __forceinline__ raw_t pack(const float* v) {
+    // two values per conversion instruction (v_cvt_pk_bf16_f32: round to nearest even, NaN kept), low half first
+    typedef float pair_f32 __attribute__((ext_vector_type(2)));
+    typedef __bf16 pair_bf16 __attribute__((ext_vector_type(2)));
     uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      w[i] = static_cast<uint32_t>(bf16_rne_hw(v[2 * i])) | (static_cast<uint32_t>(bf16_rne_hw(v[2 * i + 1])) << 16);
+      w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pair_f32{v[2 * i], v[2 * i + 1]}, pair_bf16));
     return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  static __device__ __forceinline__ float probe(const raw_t& r, float acc) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    const bf16x2_t zero = __builtin_bit_cast(bf16x2_t, 0u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w[i]), zero, acc, false);
+    return acc;
   }
 };
 template <>
@@ -100,6 +168,13 @@ struct Elem<DCQ_F16> {
       w[i] = *reinterpret_cast<const uint32_t*>(&h);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  static __device__ __forceinline__ float probe(const raw_t& r, float acc) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    const f16x2_t zero = __builtin_bit_cast(f16x2_t, 0u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w[i]), zero, acc, false);
+    return acc;
   }
 };
 
@@ -197,6 +272,8 @@ __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
   const raw_t* xin = static_cast<const raw_t*>(p.x);
   raw_t* dq_out = static_cast<raw_t*>(p.dequant);
   const int64_t raws_per_group = p.S / VEC;
+  const bool nt = p.stream_hint != 0;
+  float probe = 0.0f;
 
   constexpr int U = SINGLE ? DCQ_FUSED_U : 1;  // groups in flight per team: more bytes outstanding per lane
   for (int64_t g0 = team0; g0 < p.G; g0 += nteams * U) {
@@ -213,7 +290,10 @@ __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
       live[u] = g < p.G;
       if (SINGLE && live[u]) {
 #pragma unroll
-        for (int h = 0; h < NP; ++h) keep[u][h] = xin[g * raws_per_group + h * TL + tl];
+        for (int h = 0; h < NP; ++h) {
+          keep[u][h] = load_piece(xin + g * raws_per_group + h * TL + tl, nt);
+          probe = E::probe(keep[u][h], probe);
+        }
       }
     }
 #pragma unroll
@@ -307,7 +387,9 @@ __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) v[i] = held[u][c][i];
         } else {
-          E::unpack(xg[off], v);
+          const raw_t piece = load_piece(xg + off, nt);
+          probe = E::probe(piece, probe);
+          E::unpack(piece, v);
           if (OUTER) develop<VEC>(v, outer[u], d_outer[u], p);
         }
         if (dv[u].fast) {
@@ -316,7 +398,7 @@ __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
             f32x2 a = {v[i], v[i + 1]};
             const f32x2 zz = {z[u], z[u]}, ss = {s[u], s[u]};
             if (ZD == DCQ_ZERO_POST_SCALE) a = a + zz;
-            f32x2 t = div_fast2(a, dv[u]);
+            f32x2 t = short_significand(SK) ? div_short2(a, dv[u]) : div_fast2(a, dv[u]);
             if (ZD == DCQ_ZERO_PRE_SCALE) t = t + zz;
             f32x2 q = {clamp_f(rintf(t.x), p.q_lo, p.q_hi), clamp_f(rintf(t.y), p.q_lo, p.q_hi)};
             qv[i] = q.x;
@@ -348,16 +430,17 @@ __global__ __launch_bounds__(256) void fused_int_kernel(const FusedParams p) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) d[i] = d[i] * outer[u];
         }
-        if (dq_out) dq_out[g * raws_per_group + off] = E::pack(d);
+        if (dq_out) store_piece(dq_out + g * raws_per_group + off, E::pack(d), nt);
         if (p.codes) {
           float4* co = reinterpret_cast<float4*>(p.codes + (g * raws_per_group + off) * VEC);
 #pragma unroll
           for (int i = 0; i < VEC / 4; ++i)
-            co[i] = make_float4(qv[4 * i], qv[4 * i + 1], qv[4 * i + 2], qv[4 * i + 3]);
+            store_piece(co + i, make_float4(qv[4 * i], qv[4 * i + 1], qv[4 * i + 2], qv[4 * i + 3]), nt);
         }
       }
     }
   }
+  report_nonfinite(probe, p.nonfinite);
 }
 
 template <int ST, int ZD, int SK>
@@ -375,11 +458,14 @@ static int launch_fused(const FusedParams& pin, hipStream_t stream) {
   const int64_t threads = p.G * p.team_lanes;
   int64_t blocks = (threads + 255) / 256;
   if (p.chunks == 1) blocks = (blocks + DCQ_FUSED_U - 1) / DCQ_FUSED_U;  // several groups per team and pass
-  // measured on MI355X: a persistent grid of 8192 workgroups (32 per CU), each team looping over its groups, streams
-  // fastest from 60 MB to 1 GB (5.5-5.6 TB/s at 235 MB, 4.5-4.7 TB/s beyond the Infinity Cache); 2048 workgroups are
-  // ~8 % slower, an un-looped grid 3-8 %; non-temporal loads / stores change nothing
-  constexpr int64_t kGridCap = 8192;
+  // measured on MI355X (32768 x 8192 bf16, uint4 groups of 128, a lane holding two pieces): a team per group with no
+  // loop streams fastest -- 202 us on a persistent grid of 8192 workgroups, 190 / 186 us on 32768 / 65536 (one group
+  // per team), and with non-temporal loads and stores 190 / 176 / 171 us against 164 us for a plain copy of the same
+  // bytes.  Groups longer than a team (several chunks) keep the persistent grid.
+  const int64_t kGridCap = p.chunks == 1 ? (int64_t{1} << 22) : 8192;
   if (blocks > kGridCap) blocks = kGridCap;
+  const int64_t moved = p.G * p.S * ((p.codes ? 4 : 0) + (p.dequant ? (ST == DCQ_F32 ? 4 : 2) : 0) + (ST == DCQ_F32 ? 4 : 2));
+  p.stream_hint = moved >= kStreamBytes;
   const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 #define DCQ_LAUNCH_SINGLE(OUTER_)                                                                        \
   do {                                                                                                   \
@@ -435,7 +521,7 @@ static int fused_zero(const FusedParams& p, int zd, int sk, hipStream_t stream) 
 // lean kernel; the caller then uses the general kernel.
 int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t G, int64_t S, const float* range_max,
                          const float* range_min, int has_ratio, float ratio, void* dequant, float* codes, float* scale,
-                         float* zero, hipStream_t stream, const OuterStep* outer) {
+                         float* zero, hipStream_t stream, const OuterStep* outer, int32_t* nonfinite) {
   const int sk = st.scale.kind;
   const bool scale_ok =
       (sk == DCQ_ROUND_F32 || sk == DCQ_ROUND_F16 || sk == DCQ_ROUND_BF16 || sk == DCQ_ROUND_INT) && !st.scale.has_clamp;
@@ -477,6 +563,7 @@ int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t
   p.has_bound_max = st.has_bound_max;
   p.bound_min = st.bound_min;
   p.bound_max = st.bound_max;
+  p.nonfinite = nonfinite;
   if (outer != nullptr && outer->scale != nullptr) {
     p.outer = outer->scale;
     p.outer_lo = outer->lo;
@@ -542,6 +629,8 @@ __global__ __launch_bounds__(256) void progressive_int_kernel(const ProgressiveP
     return (group << p.team_shift) + (c % NP) * TL + (tid & (TL - 1));
   };
   int parity = 0;
+  const bool nt = p.stream_hint != 0;
+  float probe = 0.0f;
   for (int64_t row = blockIdx.x; row < pp.rows; row += gridDim.x, parity ^= 1) {
     const int64_t base = row * pp.row_pieces;
     raw_t keep[PIECES];
@@ -550,7 +639,8 @@ __global__ __launch_bounds__(256) void progressive_int_kernel(const ProgressiveP
     for (int c = 0; c < PIECES; ++c) {
       const int j = piece_of(c);
       if (j < pp.row_pieces) {
-        keep[c] = xin[base + j];
+        keep[c] = load_piece(xin + base + j, nt);
+        probe = E::probe(keep[c], probe);
         float v[VEC];
         E::unpack(keep[c], v);
 #pragma unroll
@@ -573,6 +663,7 @@ __global__ __launch_bounds__(256) void progressive_int_kernel(const ProgressiveP
     const Divisor d_outer = make_divisor(outer, 0.0f);
     // the hoisted-reciprocal division's guard (see make_divisor) for the whole row at once
     const bool row_fast = __builtin_amdgcn_readfirstlane(static_cast<int>(d_outer.fast && row_abs <= 0x1p60f)) != 0;
+    const bool short_outer = short_significand(pp.first_scale.kind);  // the row scale was rounded to that dtype
 #pragma unroll
     for (int c = 0; c < PIECES; c += NP) {
       const int j0 = piece_of(c);
@@ -585,7 +676,8 @@ __global__ __launch_bounds__(256) void progressive_int_kernel(const ProgressiveP
         if (row_fast) {
 #pragma unroll
           for (int i = 0; i < VEC; i += 2) {
-            const f32x2 t = div_fast2(f32x2{v[h][i], v[h][i + 1]}, d_outer);
+            const f32x2 x2 = {v[h][i], v[h][i + 1]};
+            const f32x2 t = short_outer ? div_short2(x2, d_outer) : div_fast2(x2, d_outer);
             v[h][i] = clamp_f(t.x, p.outer_lo, p.outer_hi);
             v[h][i + 1] = clamp_f(t.y, p.outer_lo, p.outer_hi);
           }
@@ -644,7 +736,7 @@ __global__ __launch_bounds__(256) void progressive_int_kernel(const ProgressiveP
             f32x2 a = {v[h][i], v[h][i + 1]};
             const f32x2 zz = {ze, ze}, ss = {sc, sc};
             if (ZD == DCQ_ZERO_POST_SCALE) a = a + zz;
-            f32x2 t = div_fast2(a, dv);
+            f32x2 t = short_significand(SK) ? div_short2(a, dv) : div_fast2(a, dv);
             if (ZD == DCQ_ZERO_PRE_SCALE) t = t + zz;
             const f32x2 q = {clamp_f(rintf(t.x), p.q_lo, p.q_hi), clamp_f(rintf(t.y), p.q_lo, p.q_hi)};
             qv[h][i] = q.x;
@@ -679,28 +771,35 @@ __global__ __launch_bounds__(256) void progressive_int_kernel(const ProgressiveP
           d[h][i + 1] = o.y;
         }
         const int64_t at = base + j0 + h * TL;
-        if (dq_out) dq_out[at] = E::pack(d[h]);
+        if (dq_out) store_piece(dq_out + at, E::pack(d[h]), nt);
         if (p.codes) {
           float4* co = reinterpret_cast<float4*>(p.codes + at * VEC);
 #pragma unroll
           for (int i = 0; i < VEC / 4; ++i)
-            co[i] = make_float4(qv[h][4 * i], qv[h][4 * i + 1], qv[h][4 * i + 2], qv[h][4 * i + 3]);
+            store_piece(co + i, make_float4(qv[h][4 * i], qv[h][4 * i + 1], qv[h][4 * i + 2], qv[h][4 * i + 3]), nt);
         }
       }
     }
   }
+  report_nonfinite(probe, p.nonfinite);
 }
 
 // PIECES: 16-byte pieces a thread holds (the row in registers); fewer registers, more waves in flight
 template <int ST, int ZD, int SK, int NP>
 static int progressive_launch_np(const ProgressiveParams& pp, hipStream_t stream) {
-  const dim3 grid(static_cast<unsigned>(pp.rows < 8192 ? pp.rows : 8192)), block(256);
+  // a workgroup per row, no loop up to 2^20 rows (measured on 32768 rows of 8192 bf16 values: 236 us on a persistent
+  // grid of 8192 workgroups, 226 us with one workgroup per row).  The kernel is bound by its phases, not by the
+  // vector pipe or HBM: a workgroup loads its row, waits for the row's largest magnitude, then computes and stores,
+  // and at 95 registers per lane five workgroups share a compute unit (fewer pieces of a group per lane: 84 / 67
+  // registers, but more per-group work: 244 / 258 us).
+  const ProgressiveParams& pp2 = pp;
+  const dim3 grid(static_cast<unsigned>(pp.rows < (1 << 20) ? pp.rows : (1 << 20))), block(256);
   if (pp.row_pieces <= 256 * 2) {
-    hipLaunchKernelGGL((progressive_int_kernel<ST, ZD, SK, 2, (NP > 2 ? 2 : NP)>), grid, block, 0, stream, pp);
+    hipLaunchKernelGGL((progressive_int_kernel<ST, ZD, SK, 2, (NP > 2 ? 2 : NP)>), grid, block, 0, stream, pp2);
   } else if (pp.row_pieces <= 256 * 4) {
-    hipLaunchKernelGGL((progressive_int_kernel<ST, ZD, SK, 4, NP>), grid, block, 0, stream, pp);
+    hipLaunchKernelGGL((progressive_int_kernel<ST, ZD, SK, 4, NP>), grid, block, 0, stream, pp2);
   } else {
-    hipLaunchKernelGGL((progressive_int_kernel<ST, ZD, SK, kMaxRowPieces, NP>), grid, block, 0, stream, pp);
+    hipLaunchKernelGGL((progressive_int_kernel<ST, ZD, SK, kMaxRowPieces, NP>), grid, block, 0, stream, pp2);
   }
   DCQ_LAUNCH_CHECK("progressive_int_kernel launch");
   return DCQ_OK;
@@ -758,7 +857,7 @@ extern "C" int dcq_fake_quant_progressive(const dcq_step* first, const dcq_step*
                                           float first_ratio, int32_t has_ratio, float ratio, float outer_lo,
                                           float outer_hi, int32_t deq_clamp, float deq_lo, float deq_hi, void* dequant,
                                           float* codes, float* first_scale, float* scale, float* zero,
-                                          dcq_stream_t stream) {
+                                          int32_t* nonfinite, dcq_stream_t stream) {
   using namespace dcq;
   DCQ_REQUIRE(first && last, DCQ_ERR_ARGUMENT, "step is NULL");
   DCQ_REQUIRE(rows >= 0 && row_len >= 0 && S > 0, DCQ_ERR_ARGUMENT, "bad size");
@@ -808,6 +907,10 @@ extern "C" int dcq_fake_quant_progressive(const dcq_step* first, const dcq_step*
   p.deq_clamp = deq_clamp;
   p.deq_lo = deq_lo;
   p.deq_hi = deq_hi;
+  p.nonfinite = nonfinite;
+  // no streaming hint here: with four pieces of a group per lane a wave-instruction moves 64-byte half lines, and the
+  // other half must still be in the cache when the next instruction asks for it (measured with the hint: 226 -> 254 us)
+  p.stream_hint = 0;
   pp.first_scale = first->scale;
   pp.first_q_span = first->q_span;
   pp.first_has_ratio = first_has_ratio;
@@ -846,7 +949,8 @@ namespace dcq {
 //     fully coalesced: a wave moves 128 consecutive pieces with two instructions and neighbouring lanes swap one piece
 //     each (a DPP move) so that even lanes hold groups 0..31 and odd lanes groups 32..63 of the wave's 64.
 // =============================================================================================
-constexpr int kMaxCells = 1024;
+constexpr int kMaxValueCells = 2048;  // 8 KiB: half-cells of the value table (e2m1: 48)
+constexpr int kMaxScaleCells = 1024;  // 4 KiB: cells of the scale table by exponent and leading mantissa bits (e4m3: 306)
 
 struct CodebookParams {
   dcq_step step;
@@ -867,94 +971,158 @@ struct CodebookParams {
   float level0_span;
   float* level0_out;
   float* level1_out;
+  int32_t* nonfinite;
+  int32_t stream_hint;
+  int32_t passes;       // consecutive passes of a workgroup (its share of the tensor is one contiguous run)
 };
 
 struct CodebookLut {
   float tensor[256];
   float scale[256];
-  float4 pair[kMaxCells + 1];
-  unsigned gap_bits;
-  int on_grid;
+  float value[kMaxValueCells + 1];
+  float scale_value[kMaxScaleCells + 2];
+  // per wave: min over the non-zero table values of the exponent of their lowest set bit; min over the positive
+  // scale-table values and midpoints of the trailing zero bits; the same over the values alone (24 minus this =
+  // bits of a scale's significand); bit pattern of the smallest positive midpoint of the scale table
+  unsigned reduce[4][4];
 };
 
-// Stages the tables and builds the per-cell neighbour list; returns the cell size (0: no grid, search instead).
-__device__ __forceinline__ float build_lut(const CodebookParams& p, CodebookLut& lds, float& first_cell,
-                                           unsigned& cells) {
-  const int C = p.step.tensor.codebook_size;
-  for (int i = threadIdx.x; i < C; i += blockDim.x) lds.tensor[i] = p.step.tensor.codebook[i];
-  if (p.step.scale.kind == DCQ_ROUND_CODEBOOK)
-    for (int i = threadIdx.x; i < p.step.scale.codebook_size; i += blockDim.x) lds.scale[i] = p.step.scale.codebook[i];
-  if (threadIdx.x == 0) {
-    lds.gap_bits = 0x7f7fffffu;
-    lds.on_grid = 1;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i + 1 < C; i += blockDim.x) {
-    const float gap = lds.tensor[i + 1] - lds.tensor[i];
-    if (gap > 0.0f) atomicMin(&lds.gap_bits, __float_as_uint(gap));  // positive floats order like their bit patterns
-  }
-  __syncthreads();
-  // the power of two at or below the smallest gap, then up to three halvings (tables with 1.5-spaced values)
-  float cell = __uint_as_float(lds.gap_bits & 0x7f800000u);
-  float found = 0.0f;
-  for (int attempt = 0; attempt < 4; ++attempt, cell *= 0.5f) {
-    const float inv = 1.0f / cell;  // exact
-    bool ok = cell >= 0x1p-100f && cell <= 0x1p100f;
-    if (ok) {
-      for (int i = threadIdx.x; i < C; i += blockDim.x) {
-        const float k = lds.tensor[i] * inv;
-        if (!(fabsf(k) < 0x1p22f) || k != rintf(k)) ok = false;
-      }
-      const float span = (lds.tensor[C - 1] - lds.tensor[0]) * inv;
-      if (!(span <= static_cast<float>(kMaxCells))) ok = false;
-    }
-    if (!ok) lds.on_grid = 0;
-    __syncthreads();
-    const bool all_ok = lds.on_grid != 0;
-    __syncthreads();
-    if (all_ok) {
-      found = cell;
-      break;
-    }
-    if (threadIdx.x == 0) lds.on_grid = 1;
-    __syncthreads();
-  }
-  if (found == 0.0f) return 0.0f;
-  const float inv = 1.0f / found;
-  first_cell = lds.tensor[0] * inv;
-  cells = static_cast<unsigned>(lds.tensor[C - 1] * inv - first_cell);
-  for (unsigned c = threadIdx.x; c <= cells; c += blockDim.x) {
-    const float start = (static_cast<float>(c) + first_cell) * found;  // exact
-    int lo = 0;
-    for (int bit = 1 << (31 - __clz(C)); bit; bit >>= 1) {
-      const int next = lo | bit;
-      if (next < C && lds.tensor[next] <= start) lo = next;
-    }
-    // x + x < below + above, the reference's comparison, is x < (below + above) / 2: halving the rounded sum is exact
-    const float below = lds.tensor[lo], above = lds.tensor[lo + (lo < C - 1)];
-    lds.pair[c] = make_float4(below, above, (below + above) * 0.5f, 0.0f);
-  }
-  __syncthreads();
-  return found;
+// How a value is rounded to the tensor table / a non-negative value to the scale table (0 cells: search the table)
+struct GridRound {
+  float inv_half;   // 1 / (half a cell of the value table)
+  int first;        // index of the table's first value in half-cells
+  int cells;
+  unsigned scale_shift;
+  int scale_base;   // key of the scale table's cell 0
+  int scale_cells;
+  int scale_bits;   // significand bits of a value of the scale's dtype (24: unknown / float32)
+};
+
+__device__ __forceinline__ float table_nearest(float x, const float* cb, int C) { return codebook_nearest(x, cb, C); }
+
+// Stages the tables and builds the lookup lists.
+//
+// Value table: when every table value is a multiple of a power of two `cell` (true of minifloat tables: 0.5 for
+// e2m1), every value AND every midpoint between neighbours is a multiple of cell / 2, so all x in
+// [k cell / 2, (k + 1) cell / 2) round to the same value under the reference's rule (lo if x + x < lo + hi, else hi:
+// the breakpoints are the midpoints, a midpoint itself goes up): one list entry per half-cell, filled by applying
+// that rule to the half-cell's lower edge.  x / (cell / 2) is exact (a power of two) and so is its floor.
+//
+// Scale table (inputs are magnitudes): the same idea on the bit pattern.  With `shift` = the smallest number of
+// trailing zero bits over the positive table values and positive midpoints, every breakpoint is the lower edge of a
+// cell {x : bits(x) >> shift == k}; below the smallest positive midpoint the result is the table's zero.
+// Tables that need more cells than the lists hold are searched.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v = min(v, static_cast<unsigned>(__shfl_xor(static_cast<int>(v), off, kWave)));
+  return v;
 }
 
-struct GridRound {
-  float inv_cell;  // 0: search the table
-  float first_cell;
-  unsigned cells;
-};
+__device__ __forceinline__ GridRound build_lut(const CodebookParams& p, CodebookLut& lds) {
+  const dcq_rounding& rt = p.step.tensor;
+  const dcq_rounding& rs = p.step.scale;
+  const int C = rt.codebook_size;
+  const bool scale_table = rs.kind == DCQ_ROUND_CODEBOOK;
+  const int CS = scale_table ? rs.codebook_size : 0;
+  // one table entry per thread (tables hold at most 256 values, a workgroup has 256 threads); the four minima the
+  // lists need are reduced inside each wave and meet in LDS: two barriers in all, no atomics
+  const int t = threadIdx.x;
+  unsigned low = 0xffffffffu;  // (exponent of the lowest set bit of a table value) + 1024
+  unsigned ctz_all = 23, ctz_val = 23, first_mid = 0x7f800000u;
+  if (t < C) {
+    const float v = rt.codebook[t];
+    lds.tensor[t] = v;
+    const uint32_t b = __float_as_uint(v) & 0x7fffffffu;
+    if (b != 0 && b < 0x7f800000u) {
+      const int e = static_cast<int>(b >> 23);
+      const uint32_t m = (b & 0x7fffffu) | (e ? 0x800000u : 0u);
+      low = static_cast<unsigned>((e ? e : 1) - 150 + __builtin_ctz(m) + 1024);
+    }
+  }
+  if (t < CS) {
+    const float v = rs.codebook[t];
+    lds.scale[t] = v;
+    if (v > 0.0f && v < INFINITY) {
+      ctz_val = static_cast<unsigned>(__builtin_ctz(__float_as_uint(v)));
+      ctz_all = ctz_val;
+      if (t > 0) {
+        const float mid = (rs.codebook[t - 1] + v) * 0.5f;
+        if (mid > 0.0f) {
+          ctz_all = min(ctz_all, static_cast<unsigned>(__builtin_ctz(__float_as_uint(mid))));
+          first_mid = __float_as_uint(mid);  // positive floats order like their bit patterns
+        }
+      }
+    }
+  }
+  low = wave_min_u32(low);
+  ctz_all = wave_min_u32(ctz_all);
+  ctz_val = wave_min_u32(ctz_val);
+  first_mid = wave_min_u32(first_mid);
+  if ((t & (kWave - 1)) == 0) {
+    unsigned* slot = lds.reduce[t / kWave];
+    slot[0] = low, slot[1] = ctz_all, slot[2] = ctz_val, slot[3] = first_mid;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    low = min(low, lds.reduce[w][0]);
+    ctz_all = min(ctz_all, lds.reduce[w][1]);
+    ctz_val = min(ctz_val, lds.reduce[w][2]);
+    first_mid = min(first_mid, lds.reduce[w][3]);
+  }
+  // the same in every lane: keep them in scalar registers
+  const int low_bit = static_cast<int>(__builtin_amdgcn_readfirstlane(low)) - 1024;
+  const unsigned scale_ctz = __builtin_amdgcn_readfirstlane(ctz_all);
+  const unsigned scale_value_ctz = __builtin_amdgcn_readfirstlane(ctz_val);
+  const unsigned scale_first = __builtin_amdgcn_readfirstlane(first_mid);
+  GridRound gr{};
+  gr.scale_bits = rs.kind == DCQ_ROUND_F16 ? 11 : (rs.kind == DCQ_ROUND_BF16 || rs.kind == DCQ_ROUND_INT) ? 8
+                  : scale_table ? 24 - static_cast<int>(scale_value_ctz) : 24;
+  {
+    const int low = low_bit;
+    if (low >= -100 && low <= 100) {
+      const float inv_half = ldexpf(1.0f, 1 - low);
+      const float first = lds.tensor[0] * inv_half, last = lds.tensor[C - 1] * inv_half;
+      // the clamp range must lie inside the table, or an index could fall outside the list
+      const bool inside = rt.lo >= lds.tensor[0] && rt.hi <= lds.tensor[C - 1];
+      if (inside && fabsf(first) < 0x1p22f && fabsf(last) < 0x1p22f && last - first <= static_cast<float>(kMaxValueCells)) {
+        gr.inv_half = inv_half;
+        gr.first = static_cast<int>(first);
+        gr.cells = static_cast<int>(last - first);
+      }
+    }
+  }
+  if (scale_table && scale_first < 0x7f800000u && rs.hi <= lds.scale[CS - 1] && rs.hi > 0.0f) {
+    const unsigned shift = scale_ctz;
+    const int base = static_cast<int>(scale_first >> shift) - 1;  // cell 0: everything below the first midpoint
+    const int cells = static_cast<int>(__float_as_uint(rs.hi) >> shift) - base;
+    if (cells >= 1 && cells <= kMaxScaleCells) {
+      gr.scale_shift = shift;
+      gr.scale_base = base;
+      gr.scale_cells = cells;
+    }
+  }
+  if (gr.cells > 0) {
+    const float half = 1.0f / gr.inv_half;  // exact
+    for (int c = threadIdx.x; c <= gr.cells; c += blockDim.x)
+      lds.value[c] = table_nearest(static_cast<float>(c + gr.first) * half, lds.tensor, C);
+  }
+  if (gr.scale_cells > 0) {
+    for (int c = threadIdx.x; c <= gr.scale_cells; c += blockDim.x) {
+      const float edge = c == 0 ? 0.0f : __uint_as_float(static_cast<unsigned>(c + gr.scale_base) << gr.scale_shift);
+      lds.scale_value[c] = table_nearest(edge, lds.scale, CS);
+    }
+  }
+  __syncthreads();
+  return gr;
+}
 
 __device__ __forceinline__ float round_to_table(float t, const dcq_rounding& r, const GridRound& gr,
                                                 const CodebookLut& lds) {
   float y;
   const float c = clamp_f(t, r.lo, r.hi);  // == fminf(fmaxf(t, lo), hi), NaN included (both give lo)
-  if (gr.inv_cell != 0.0f) {
-    // cell number relative to the table's first value; the float -> unsigned conversion truncates (a floor: the
-    // operand is >= 0, anything below converts to 0).  The one rounding of the fused multiply-add can only move an x
-    // within half an ulp of a cell's upper edge into the next cell, whose pair decides such an x the same way.
-    const unsigned cell = min(static_cast<unsigned>(__builtin_fmaf(c, gr.inv_cell, -gr.first_cell)), gr.cells);
-    const float4 nb = lds.pair[cell];  // below, above, (below + above) / 2
-    y = c < nb.z ? nb.x : nb.y;
+  if (gr.cells > 0) {
+    y = lds.value[static_cast<int>(floorf(c * gr.inv_half)) - gr.first];
   } else {
     y = codebook_nearest(c, lds.tensor, r.codebook_size);
   }
@@ -962,41 +1130,92 @@ __device__ __forceinline__ float round_to_table(float t, const dcq_rounding& r, 
   return y;
 }
 
+// apply_rounding of a magnitude (v >= 0) with the scale's dtype
+__device__ __forceinline__ float round_scale_magnitude(float v, const dcq_rounding& r, const GridRound& gr,
+                                                       const CodebookLut& lds) {
+  if (r.kind != DCQ_ROUND_CODEBOOK || gr.scale_cells == 0) return apply_rounding(r, v, lds.scale);
+  const float c = clamp_f(v, r.lo, r.hi);
+  const int k = static_cast<int>(__float_as_uint(c) >> gr.scale_shift) - gr.scale_base;
+  float y = lds.scale_value[k > 0 ? k : 0];
+  if (r.has_clamp) y = clamp_f(y, r.clamp_lo, r.clamp_hi);
+  return y;
+}
+
+// x / d.s for a divisor that is the same for every group (the quantization span, the per-tensor scale level)
+__device__ __forceinline__ float div_uniform(float x, const Divisor& d) {
+  return (d.fast && fabsf(x) <= 0x1p60f) ? div_fast(x, d) : x / d.s;
+}
+
+struct UniformDivisors {
+  Divisor q_span, level0;
+};
+
 // Scale of one group from its largest magnitude (quantizer/impl/scale.py:46-62 for two levels).
-__device__ __forceinline__ float table_group_scale(const CodebookParams& p, const CodebookLut& lds, float vmax,
-                                                   float level0, float& level1) {
+__device__ __forceinline__ float table_group_scale(const CodebookParams& p, const CodebookLut& lds, const GridRound& gr,
+                                                   const UniformDivisors& ud, float vmax, float level0, float& level1) {
   const dcq_step& st = p.step;
   if (p.has_ratio) vmax = vmax * p.ratio;
   if (st.has_bound_max) vmax = fminf(vmax, st.bound_max);
   float s;
   if (p.tensor_absmax) {
-    level1 = apply_rounding(st.scale, fabsf(vmax / st.q_span) / level0, lds.scale);
+    level1 = round_scale_magnitude(div_uniform(fabsf(div_uniform(vmax, ud.q_span)), ud.level0), st.scale, gr, lds);
     s = level1 * level0;
   } else {
-    s = apply_rounding(st.scale, fabsf(vmax / st.q_span), lds.scale);
+    s = round_scale_magnitude(fabsf(div_uniform(vmax, ud.q_span)), st.scale, gr, lds);
     level1 = s;
   }
   return s == 0.0f ? 1.0f : s;
 }
 
-// N pieces of one group held by one lane: quantize in place (v -> de-quantized), codes to q
-template <int N>
-__device__ __forceinline__ void quantize_to_table(float* v, float* q, float s, float local_abs, const dcq_rounding& r,
-                                                  const GridRound& gr, const CodebookLut& lds) {
-  const Divisor d = make_divisor(s, local_abs);
-  if (d.fast) {
+// (int)floorf(x) in one instruction
+__device__ __forceinline__ int floor_to_int(float x) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// N values of one group held by one lane: quantize in place (v -> de-quantized), codes to q.  The list form has no
+// branch per element: the caller has checked, for the whole wave, that the value list exists, that the table's own
+// clamp is the only one and that every lane's divisor is inside the hoisted-reciprocal guard.
+template <int N, bool SHORT>
+__device__ __forceinline__ void quantize_by_list(float* v, float* q, float s, const Divisor& d, float lo, float hi,
+                                                 float inv_half, const float* list) {
 #pragma unroll
-    for (int i = 0; i < N; i += 2) {
-      const f32x2 t = div_fast2(f32x2{v[i], v[i + 1]}, d);
-      q[i] = round_to_table(t.x, r, gr, lds);
-      q[i + 1] = round_to_table(t.y, r, gr, lds);
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < N; ++i) q[i] = round_to_table(v[i] / s, r, gr, lds);
+  for (int i = 0; i < N; i += 2) {
+    const f32x2 x2 = {v[i], v[i + 1]};
+    const f32x2 t = SHORT ? div_short2(x2, d) : div_fast2(x2, d);
+    // clamp (NaN -> lo, as fminf(fmaxf(t, lo), hi)), half-cell number (exact: a power-of-two factor, then floor)
+    q[i] = list[floor_to_int(clamp_f(t.x, lo, hi) * inv_half)];
+    q[i + 1] = list[floor_to_int(clamp_f(t.y, lo, hi) * inv_half)];
   }
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = q[i] * s;
+  for (int i = 0; i < N; i += 2) {
+    const f32x2 o = f32x2{q[i], q[i + 1]} * f32x2{s, s};
+    v[i] = o.x;
+    v[i + 1] = o.y;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void quantize_to_table(float* v, float* q, float s, float local_abs, bool short_scale,
+                                                  const dcq_rounding& r, const GridRound& gr, const CodebookLut& lds) {
+  const Divisor d = make_divisor(s, local_abs);
+  const bool by_list = gr.cells > 0 && !r.has_clamp && __builtin_amdgcn_ballot_w64(!d.fast) == 0;
+  if (by_list) {
+    const float* list = lds.value - gr.first;
+    if (short_scale) {
+      quantize_by_list<N, true>(v, q, s, d, r.lo, r.hi, gr.inv_half, list);
+    } else {
+      quantize_by_list<N, false>(v, q, s, d, r.lo, r.hi, gr.inv_half, list);
+    }
+    return;
+  }
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) {
+    const float t = d.fast ? div_fast(v[i], d) : v[i] / s;
+    q[i] = round_to_table(t, r, gr, lds);
+    v[i] = q[i] * s;
+  }
 }
 
 template <typename RAW>
@@ -1016,14 +1235,17 @@ __global__ __launch_bounds__(256) void fused_table_kernel(const CodebookParams p
   using raw_t = typename E::raw_t;
   constexpr int VEC = E::kVec;
   __shared__ CodebookLut lds;
-  GridRound gr;
-  gr.first_cell = 0.0f;
-  gr.cells = 0;
-  const float cell = build_lut(p, lds, gr.first_cell, gr.cells);
-  gr.inv_cell = cell != 0.0f ? 1.0f / cell : 0.0f;
+  const GridRound gr = build_lut(p, lds);
   const dcq_step& st = p.step;
   const raw_t* xin = static_cast<const raw_t*>(p.x);
   raw_t* dq_out = static_cast<raw_t*>(p.dequant);
+  const bool nt = p.stream_hint != 0;
+  // significand of a group scale: a value of the scale's dtype, times the per-tensor level when there are two (a
+  // float8 level under a 16-bit one: 4 + 11 bits); up to 16 bits take the one-correction division
+  const int level0_bits = !p.tensor_absmax ? 0 : p.level0.kind == DCQ_ROUND_F16 ? 11 : p.level0.kind == DCQ_ROUND_BF16 ? 8 : 24;
+  const bool short_scale = gr.scale_bits + level0_bits <= 16;
+  UniformDivisors ud;
+  ud.q_span = make_divisor(st.q_span, 0.0f);
 
   float level0 = 1.0f;
   if (p.tensor_absmax) {
@@ -1033,18 +1255,23 @@ __global__ __launch_bounds__(256) void fused_table_kernel(const CodebookParams p
     level0 = apply_rounding(p.level0, fabsf(top / st.q_span) / p.level0_span, nullptr);
     if (blockIdx.x == 0 && threadIdx.x == 0 && p.level0_out) *p.level0_out = level0;
   }
+  ud.level0 = make_divisor(level0, 0.0f);
 
+  float probe = 0.0f;
   if (PAIRED) {
     const int lane = threadIdx.x & 63;
     const bool odd = lane & 1;
-    const int64_t wave = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
-    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * 4;
+    // a workgroup owns `passes` consecutive runs of 4 waves x 128 pieces
+    const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * p.passes) * 4 + (threadIdx.x >> 6);
     const int64_t pieces = p.G * 2;
-    for (int64_t w = wave; w * 64 < p.G; w += nwaves) {
+    for (int pass = 0; pass < p.passes; ++pass) {
+      const int64_t w = wave0 + static_cast<int64_t>(pass) * 4;
+      if (w * 64 >= p.G) break;
       const int64_t r0 = w * 128 + lane, r1 = r0 + 64;
       raw_t a{}, b{};
-      if (r0 < pieces) a = xin[r0];
-      if (r1 < pieces) b = xin[r1];
+      if (r0 < pieces) a = load_piece(xin + r0, nt);
+      if (r1 < pieces) b = load_piece(xin + r1, nt);
+      if (p.nonfinite) probe = E::probe(b, E::probe(a, probe));
       // even lanes give away their second piece, odd lanes their first
       const raw_t got = swap_with_neighbour(odd ? a : b);
       const raw_t first = odd ? got : a, second = odd ? b : got;
@@ -1056,8 +1283,8 @@ __global__ __launch_bounds__(256) void fused_table_kernel(const CodebookParams p
 #pragma unroll
       for (int i = 0; i < 2 * VEC; ++i) mx = fmaxf(mx, fabsf(v[i]));
       float level1;
-      const float s = table_group_scale(p, lds, mx, level0, level1);
-      quantize_to_table<2 * VEC>(v, q, s, mx, st.tensor, gr, lds);
+      const float s = table_group_scale(p, lds, gr, ud, mx, level0, level1);
+      quantize_to_table<2 * VEC>(v, q, s, mx, short_scale, st.tensor, gr, lds);
       if (g < p.G) {
         if (p.scale_out) p.scale_out[g] = s;
         if (p.zero_out) p.zero_out[g] = 0.0f;
@@ -1065,33 +1292,38 @@ __global__ __launch_bounds__(256) void fused_table_kernel(const CodebookParams p
         if (p.codes) {
           float4* co = reinterpret_cast<float4*>(p.codes + g * (2 * VEC));
 #pragma unroll
-          for (int i = 0; i < 2 * VEC / 4; ++i) co[i] = make_float4(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
+          for (int i = 0; i < 2 * VEC / 4; ++i)
+            store_piece(co + i, make_float4(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]), nt);
         }
       }
       if (dq_out) {
         const raw_t f = E::pack(v), sd = E::pack(v + VEC);
         const raw_t back = swap_with_neighbour(odd ? f : sd);
         const raw_t oa = odd ? back : f, ob = odd ? sd : back;
-        if (r0 < pieces) dq_out[r0] = oa;
-        if (r1 < pieces) dq_out[r1] = ob;
+        if (r0 < pieces) store_piece(dq_out + r0, oa, nt);
+        if (r1 < pieces) store_piece(dq_out + r1, ob, nt);
       }
     }
   } else {
     const int TL = p.team_lanes;
     const int tl = threadIdx.x & (TL - 1);
-    const int64_t team0 = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> p.team_shift;
-    const int64_t nteams = (static_cast<int64_t>(gridDim.x) * 256) >> p.team_shift;
-    for (int64_t g = team0; g < p.G; g += nteams) {
+    const int64_t teams_per_pass = 256 >> p.team_shift;
+    const int64_t team0 = static_cast<int64_t>(blockIdx.x) * p.passes * teams_per_pass + (threadIdx.x >> p.team_shift);
+    for (int pass = 0; pass < p.passes; ++pass) {
+      const int64_t g = team0 + pass * teams_per_pass;
+      if (g >= p.G) break;  // (whole teams leave together)
       const int64_t at = g * TL + tl;
       float v[VEC], q[VEC];
-      E::unpack(xin[at], v);
+      const raw_t piece = load_piece(xin + at, nt);
+      if (p.nonfinite) probe = E::probe(piece, probe);
+      E::unpack(piece, v);
       float mx = 0.0f;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) mx = fmaxf(mx, fabsf(v[i]));
       const float vmax = team_reduce<true>(mx, TL);
       float level1;
-      const float s = table_group_scale(p, lds, vmax, level0, level1);
-      quantize_to_table<VEC>(v, q, s, mx, st.tensor, gr, lds);
+      const float s = table_group_scale(p, lds, gr, ud, vmax, level0, level1);
+      quantize_to_table<VEC>(v, q, s, mx, short_scale, st.tensor, gr, lds);
       if (tl == 0) {
         if (p.scale_out) p.scale_out[g] = s;
         if (p.zero_out) p.zero_out[g] = 0.0f;
@@ -1100,23 +1332,32 @@ __global__ __launch_bounds__(256) void fused_table_kernel(const CodebookParams p
       if (p.codes) {
         float4* co = reinterpret_cast<float4*>(p.codes + at * VEC);
 #pragma unroll
-        for (int i = 0; i < VEC / 4; ++i) co[i] = make_float4(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
+        for (int i = 0; i < VEC / 4; ++i)
+          store_piece(co + i, make_float4(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]), nt);
       }
-      if (dq_out) dq_out[at] = E::pack(v);
+      if (dq_out) store_piece(dq_out + at, E::pack(v), nt);
     }
   }
+  report_nonfinite(probe, p.nonfinite);
 }
 
 template <int ST>
-static int launch_table(const CodebookParams& p, bool paired, hipStream_t stream) {
-  constexpr int64_t kGridCap = 8192;
+static int launch_table(CodebookParams p, bool paired, hipStream_t stream) {
+  // Every workgroup builds the lookup lists (three barriers, a few hundred table searches) before it streams, so it
+  // takes `passes` consecutive passes of 8 KiB of input -- one contiguous run -- to spread that cost; small tensors
+  // keep one pass per workgroup so that the chip fills.
+  // (measured on 32768 x 8192 bf16, NVFP4: 1 pass 387 us, 4 or 8 passes 230-235 us, 32 passes 246 us)
+  const int64_t per_pass = paired ? 256 : (256 >> p.team_shift);  // groups per workgroup and pass
+  const int64_t total = (p.G + per_pass - 1) / per_pass;
+  int passes = 1;
+  while (passes < 8 && total / (passes * 2) >= 4096) passes *= 2;
+  p.passes = passes;
+  const int64_t width = ST == DCQ_F32 ? 4 : 2;
+  p.stream_hint = p.G * p.S * (width + (p.dequant ? width : 0) + (p.codes ? 4 : 0)) >= kStreamBytes;
+  const int64_t blocks = (total + passes - 1) / passes;
   if (paired) {
-    int64_t blocks = (p.G + 255) / 256;  // 64 groups per wave and pass
-    if (blocks > kGridCap) blocks = kGridCap;
     hipLaunchKernelGGL((fused_table_kernel<ST, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
   } else {
-    int64_t blocks = (p.G * p.team_lanes + 255) / 256;
-    if (blocks > kGridCap) blocks = kGridCap;
     hipLaunchKernelGGL((fused_table_kernel<ST, false>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, p);
   }
   DCQ_LAUNCH_CHECK("fused_table_kernel launch");
@@ -1127,7 +1368,7 @@ static int launch_table(const CodebookParams& p, bool paired, hipStream_t stream
 int try_launch_fused_table(const dcq_step& st, const void* x, int storage, int64_t G, int64_t S, int has_ratio,
                            float ratio, const float* tensor_absmax, const dcq_rounding* level0, float level0_span,
                            void* dequant, float* codes, float* level0_out, float* level1_out, float* scale,
-                           float* zero, hipStream_t stream) {
+                           float* zero, hipStream_t stream, int32_t* nonfinite) {
   if (st.tensor.kind != DCQ_ROUND_CODEBOOK || st.zero_domain != DCQ_ZERO_NONE) return DCQ_ERR_UNSUPPORTED;
   const int vec = storage == DCQ_F32 ? 4 : 8;
   auto aligned = [](const void* ptr, uintptr_t a) { return ptr == nullptr || (reinterpret_cast<uintptr_t>(ptr) % a) == 0; };
@@ -1135,6 +1376,7 @@ int try_launch_fused_table(const dcq_step& st, const void* x, int storage, int64
   const int64_t n = S / vec;
   const bool paired = n == 2;
   if (!paired && (n > 64 || (n & (n - 1)) != 0)) return DCQ_ERR_UNSUPPORTED;
+  if (G >= (int64_t{1} << 38)) return DCQ_ERR_UNSUPPORTED;
   CodebookParams p{};
   p.step = st;
   p.x = x;
@@ -1155,6 +1397,7 @@ int try_launch_fused_table(const dcq_step& st, const void* x, int storage, int64
   }
   p.level0_out = level0_out;
   p.level1_out = level1_out;
+  p.nonfinite = nonfinite;
   switch (storage) {
     case DCQ_F32:
       return launch_table<DCQ_F32>(p, paired, stream);
@@ -1218,13 +1461,19 @@ __global__ __launch_bounds__(256) void smooth_int_kernel(const SmoothParams sp) 
   const int chunks = SINGLE ? 1 : p.chunks;
   // whole waves iterate together (the trip count is taken from the wave's first team), dead teams redo group 0
   const int64_t wave_team0 = __shfl(team0, 0, kWave);
+  float probe = 0.0f;
   for (int64_t gw = wave_team0, g0 = team0; gw < p.G; gw += nteams, g0 += nteams) {
     const bool live = g0 < p.G;
     const int64_t g = live ? g0 : 0;
     const raw_t* xg = xin + g * raws_per_group;
     const int64_t c_base = (g % sp.groups_per_row) * p.S;
     raw_t keep;
-    if (SINGLE) keep = xg[tl];
+    if (SINGLE) {
+      keep = xg[tl];
+      if (live) probe = E::probe(keep, probe);
+    } else if (live) {
+      for (int c = 0; c < chunks; ++c) probe = E::probe(xg[static_cast<int64_t>(c) * TL + tl], probe);
+    }
     for (int k = 0; k < sp.K; ++k) {
       const float* cs = sp.chan_scale + static_cast<int64_t>(k) * sp.C + c_base;
       // ---- pass 1: range of the smoothed values
@@ -1285,7 +1534,7 @@ __global__ __launch_bounds__(256) void smooth_int_kernel(const SmoothParams sp) 
           const float xs = sp.divide_first ? v[i] / m[i] : v[i] * m[i];
           float a = xs;
           if (ZD == DCQ_ZERO_POST_SCALE) a = a + ze;
-          float t = dv.fast ? div_fast(a, dv) : a / sc;
+          float t = dv.fast ? (short_significand(SK) ? div_short(a, dv) : div_fast(a, dv)) : a / sc;
           if (ZD == DCQ_ZERO_PRE_SCALE) t = t + ze;
           const float q = clamp_f(rintf(t), p.q_lo, p.q_hi);
           const float d = from_code<ZD>(q, sc, ze);
@@ -1307,6 +1556,7 @@ __global__ __launch_bounds__(256) void smooth_int_kernel(const SmoothParams sp) 
       }
     }
   }
+  report_nonfinite(probe, p.nonfinite);
 }
 
 template <int ST, int ZD, int SK>
@@ -1348,12 +1598,13 @@ static int smooth_zero(const SmoothParams& sp, int zd, int sk, hipStream_t strea
 }
 
 __global__ void selftest_division_kernel(const float* x, const float* sv, float* fast, float* ref, int* used_fast,
-                                         int64_t n) {
+                                         float* one_step, int64_t n) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Divisor d = make_divisor(sv[i], fabsf(x[i]));
   const f32x2 a = {x[i], x[i]};
   fast[i] = d.fast ? div_fast2(a, d).x : x[i] / sv[i];
+  if (one_step) one_step[i] = d.fast ? div_short2(a, d).y : x[i] / sv[i];
   ref[i] = x[i] / sv[i];
   used_fast[i] = d.fast ? 1 : 0;
 }
@@ -1361,10 +1612,10 @@ __global__ void selftest_division_kernel(const float* x, const float* sv, float*
 }  // namespace dcq
 
 extern "C" int dcq_selftest_division(const float* x, const float* s, float* fast, float* ref, int32_t* used_fast,
-                                     int64_t n, dcq_stream_t stream) {
+                                     float* one_step, int64_t n, dcq_stream_t stream) {
   if (n <= 0) return DCQ_OK;
   hipLaunchKernelGGL(dcq::selftest_division_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, s, fast, ref, used_fast, n);
+                     static_cast<hipStream_t>(stream), x, s, fast, ref, used_fast, one_step, n);
   DCQ_LAUNCH_CHECK("selftest_division_kernel launch");
   return DCQ_OK;
 }
@@ -1372,7 +1623,7 @@ extern "C" int dcq_selftest_division(const float* x, const float* s, float* fast
 extern "C" int dcq_smooth_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
                                             int64_t groups_per_row, const float* chan_scale, int32_t K, int32_t mode,
                                             int32_t has_ratio, float ratio, void* dequant, float* errors, double degree,
-                                            const uint16_t* pow_table, dcq_stream_t stream) {
+                                            const uint16_t* pow_table, int32_t* nonfinite, dcq_stream_t stream) {
   using namespace dcq;
   DCQ_REQUIRE(step != nullptr, DCQ_ERR_ARGUMENT, "step is NULL");
   DCQ_REQUIRE(G >= 0 && S > 0 && groups_per_row > 0 && K > 0, DCQ_ERR_ARGUMENT, "bad sizes");
@@ -1418,6 +1669,7 @@ extern "C" int dcq_smooth_fake_quant_groups(const dcq_step* step, const void* x,
   p.has_bound_max = st.has_bound_max;
   p.bound_min = st.bound_min;
   p.bound_max = st.bound_max;
+  p.nonfinite = nonfinite;
   sp.chan_scale = chan_scale;
   sp.groups_per_row = static_cast<int32_t>(groups_per_row);
   sp.C = groups_per_row * S;

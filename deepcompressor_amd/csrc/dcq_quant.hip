@@ -71,6 +71,7 @@ struct GroupParams {
   float* zero_out;
   float* vmax_out;
   float* vmin_out;
+  int32_t* nonfinite;  // |= 4 when an element of x is NaN or +-Inf (NULL: not wanted)
 };
 
 constexpr int kBlock = 256;
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
     };
     Chunk<in_t, VEC> keep;  // the group's data when it fits one pass
     float s = 1.0f, z = 0.0f;
+    float probe = 0.0f;  // stays 0 unless an element is NaN or +-Inf (x * 0 is NaN then)
 
     if (MODE == kFused || MODE == kRangeOnly) {
       float vmax, vmin = 0.0f;
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
             float v = In::load(ch.v[i]);
+            if (MODE == kRangeOnly) probe = __builtin_fmaf(v, 0.0f, probe);
             if (p.outer) v = fminf(fmaxf(by_outer(v), p.outer_lo), p.outer_hi);
             if (ZD == DCQ_ZERO_NONE) {
               mx = fmaxf(mx, fabsf(v));
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
             p.vmax_out[g] = vmax;
             if (ZD != DCQ_ZERO_NONE) p.vmin_out[g] = vmin;
           }
+          if (p.nonfinite != nullptr && probe != probe) atomicOr(p.nonfinite, 4);
           continue;
         }
         // DynamicRange.measure: ratio, then the PreScale sign clamp
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
         float q;
         if (want_q) {
           float v = In::load(ch.v[i]);
+          probe = __builtin_fmaf(v, 0.0f, probe);
           if (p.outer) v = fminf(fmaxf(by_outer(v), p.outer_lo), p.outer_hi);
           float t = v;
           if (ZD == DCQ_ZERO_POST_SCALE) t = t + z;
@@ -240,6 +245,7 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupParams p) {
       if (p.dequant) store_chunk<out_t, VEC>(static_cast<out_t*>(p.dequant) + g * p.S + off, dq);
       if (p.codes) store_chunk<float, VEC>(p.codes + g * p.S + off, qc);
     }
+    if (p.nonfinite != nullptr && probe != probe) atomicOr(p.nonfinite, 4);
   }
 }
 
@@ -499,31 +505,73 @@ __global__ __launch_bounds__(kBlock) void prescale_kernel(const typename Storage
   }
 }
 
-// max |x| over a whole tensor into *out (which the caller has zeroed): non-negative floats order like their bit
-// patterns, so the workgroups' maxima meet in one integer atomic; any order gives the same bits.
+// max |x| over a whole tensor into *out (which the caller has zeroed): magnitudes order like their bit patterns (NaN
+// patterns above Inf above every finite value), so the reduction runs on integers -- for the 16-bit types on the packed
+// words as loaded, one v_pk_max_u16 per two elements -- and the workgroups' maxima meet in one integer atomic; any order
+// gives the same bits.  A pure read: four independent non-temporal 16-byte loads in flight per lane and two workgroups
+// per compute unit (measured on 537 MB of bf16: 77 us = 7.0 TB/s; one plain load in flight on 2048 workgroups, the
+// earlier form, 95 us; more or fewer workgroups lose 5-10 %).  A maximum at or above the Inf pattern means the tensor
+// holds Inf or NaN: reported through `nonfinite` (|= 4), and the stored maximum is then Inf.
+constexpr int kAbsmaxLoads = 4;
+
 template <int ST>
-__global__ __launch_bounds__(kBlock) void tensor_absmax_kernel(const typename Storage<ST>::elem_t* x, int64_t n,
-                                                               float* out) {
-  using elem_t = typename Storage<ST>::elem_t;
+__global__ __launch_bounds__(kBlock) void tensor_absmax_kernel(const typename Storage<ST>::elem_t* x0, int64_t n0,
+                                                               int64_t head, float* out, int32_t* nonfinite) {
   constexpr int VEC = Storage<ST>::kVec;
-  __shared__ float red[kBlock / kWave];
-  float m = 0.0f;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ uint32_t red[kBlock / kWave];
+  // the first `head` elements (up to the first 16-byte boundary) and the last n % VEC are read one by one
+  const typename Storage<ST>::elem_t* x = x0 + head;
+  const int64_t n = n0 - head;
+  const u32x4* x4 = reinterpret_cast<const u32x4*>(x);
   const int64_t chunks = n / VEC;
-  for (int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; c < chunks;
-       c += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const Chunk<elem_t, VEC> ch = load_chunk<elem_t, VEC>(x + c * VEC);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  uint32_t acc = 0;  // float32: magnitude bits; 16-bit types: one running maximum per half word
+  for (int64_t c = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; c < chunks; c += stride * kAbsmaxLoads) {
+    u32x4 r[kAbsmaxLoads];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) m = fmaxf(m, fabsf(Storage<ST>::load(ch.v[i])));
+    for (int u = 0; u < kAbsmaxLoads; ++u) {
+      const int64_t i = c + u * stride;
+      r[u] = i < chunks ? __builtin_nontemporal_load(x4 + i) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < kAbsmaxLoads; ++u) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (ST == DCQ_F32) {
+          acc = max(acc, r[u][k] & 0x7fffffffu);
+        } else {
+          const uint32_t a = r[u][k] & 0x7fff7fffu;
+          uint32_t m;
+          asm("v_pk_max_u16 %0, %1, %2" : "=v"(m) : "v"(acc), "v"(a));
+          acc = m;
+        }
+      }
+    }
   }
-  if (blockIdx.x == 0)
-    for (int64_t i = chunks * VEC + threadIdx.x; i < n; i += kBlock) m = fmaxf(m, fabsf(Storage<ST>::load(x[i])));
-  m = team_max(m, kWave);
-  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = m;
+  // magnitude bits widened to the float32 pattern of the same value (bf16: shift; f16: convert, Inf / NaN kept)
+  auto widen = [](uint32_t half) -> uint32_t {
+    if (ST == DCQ_BF16) return half << 16;
+    return __float_as_uint(f16_to_f32(static_cast<uint16_t>(half)));
+  };
+  uint32_t top = ST == DCQ_F32 ? acc : max(widen(acc & 0xffffu), widen(acc >> 16));
+  if (ST != DCQ_F32) top &= 0x7fffffffu;
+  if (blockIdx.x == 0) {
+    for (int64_t i = chunks * VEC + threadIdx.x; i < n; i += kBlock)
+      top = max(top, __float_as_uint(fabsf(Storage<ST>::load(x[i]))));
+    if (threadIdx.x < head) top = max(top, __float_as_uint(fabsf(Storage<ST>::load(x0[threadIdx.x]))));
+  }
+  for (int off = kWave / 2; off > 0; off >>= 1) top = max(top, static_cast<uint32_t>(__shfl_xor(static_cast<int>(top), off, kWave)));
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = top;
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int w = 1; w < kBlock / kWave; ++w) m = fmaxf(m, red[w]);
-    atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+    for (int w = 1; w < kBlock / kWave; ++w) top = max(top, red[w]);
+    if (top >= 0x7f800000u) {
+      if (nonfinite != nullptr) atomicOr(nonfinite, 4);
+      top = 0x7f800000u;
+    }
+    atomicMax(reinterpret_cast<unsigned int*>(out), top);
   }
 }
 
@@ -597,7 +645,8 @@ int dcq_round_to_codebook(const void* x, void* y, int64_t n, int32_t storage, co
 
 int dcq_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
                           const float* range_max, const float* range_min, int32_t has_ratio, float ratio,
-                          void* dequant, float* codes, float* scale, float* zero, dcq_stream_t stream) {
+                          void* dequant, float* codes, float* scale, float* zero, int32_t* nonfinite,
+                          dcq_stream_t stream) {
   int rc = validate_step(step);
   if (rc != DCQ_OK) return rc;
   DCQ_REQUIRE(G >= 0 && S >= 0, DCQ_ERR_ARGUMENT, "negative size");
@@ -611,11 +660,11 @@ int dcq_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, 
   DCQ_REQUIRE(!(range_max && has_ratio), DCQ_ERR_UNSUPPORTED,
               "ratio together with a bounding range: use dcq_group_range + dcq_range_to_scale");
   rc = try_launch_fused_int(*step, x, storage, G, S, range_max, range_min, has_ratio, ratio, dequant, codes, scale,
-                            zero, static_cast<hipStream_t>(stream));
+                            zero, static_cast<hipStream_t>(stream), nullptr, nonfinite);
   if (rc != DCQ_ERR_UNSUPPORTED) return rc;
   if (range_max == nullptr) {
     rc = try_launch_fused_table(*step, x, storage, G, S, has_ratio, ratio, nullptr, nullptr, 0.0f, dequant, codes,
-                                nullptr, nullptr, scale, zero, static_cast<hipStream_t>(stream));
+                                nullptr, nullptr, scale, zero, static_cast<hipStream_t>(stream), nonfinite);
     if (rc != DCQ_ERR_UNSUPPORTED) return rc;
   }
   GroupParams p{};
@@ -631,6 +680,7 @@ int dcq_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, 
   p.codes = codes;
   p.scale_out = scale;
   p.zero_out = zero;
+  p.nonfinite = nonfinite;
   return dispatch_storage<kFused>(p, storage, storage, static_cast<hipStream_t>(stream));
 }
 
@@ -638,7 +688,7 @@ int dcq_fake_quant_groups_outer(const dcq_step* step, const void* x, int32_t sto
                                 const float* outer, float outer_lo, float outer_hi, int32_t deq_clamp, float deq_lo,
                                 float deq_hi, const float* range_max, const float* range_min, int32_t has_ratio,
                                 float ratio, void* dequant, int32_t out_storage, float* codes, float* scale, float* zero,
-                                dcq_stream_t stream) {
+                                int32_t* nonfinite, dcq_stream_t stream) {
   int rc = validate_step(step);
   if (rc != DCQ_OK) return rc;
   DCQ_REQUIRE(G >= 0 && S >= 0, DCQ_ERR_ARGUMENT, "negative size");
@@ -653,7 +703,7 @@ int dcq_fake_quant_groups_outer(const dcq_step* step, const void* x, int32_t sto
   if (dequant == nullptr || out_storage == storage) {
     const OuterStep prev{outer, outer_lo, outer_hi, deq_clamp, deq_lo, deq_hi};
     rc = try_launch_fused_int(*step, x, storage, G, S, range_max, range_min, has_ratio, ratio, dequant, codes, scale,
-                              zero, static_cast<hipStream_t>(stream), &prev);
+                              zero, static_cast<hipStream_t>(stream), &prev, nonfinite);
     if (rc != DCQ_ERR_UNSUPPORTED) return rc;
   }
   GroupParams p{};
@@ -675,13 +725,14 @@ int dcq_fake_quant_groups_outer(const dcq_step* step, const void* x, int32_t sto
   p.codes = codes;
   p.scale_out = scale;
   p.zero_out = zero;
+  p.nonfinite = nonfinite;
   return dispatch_storage<kFused>(p, storage, dequant ? out_storage : storage, static_cast<hipStream_t>(stream));
 }
 
 int dcq_fake_quant_groups_two_level(const dcq_step* step, const dcq_rounding* level0, float level0_span, const void* x,
                                     int32_t storage, int64_t G, int64_t S, int32_t has_ratio, float ratio,
                                     float* tensor_absmax, void* dequant, float* codes, float* level0_out,
-                                    float* level1_out, float* scale, dcq_stream_t stream) {
+                                    float* level1_out, float* scale, int32_t* nonfinite, dcq_stream_t stream) {
   int rc = validate_step(step);
   if (rc != DCQ_OK) return rc;
   DCQ_REQUIRE(level0 != nullptr && level0_span > 0.0f, DCQ_ERR_ARGUMENT, "first scale level is missing");
@@ -695,19 +746,27 @@ int dcq_fake_quant_groups_two_level(const dcq_step* step, const dcq_rounding* le
   rc = hip_check(hipMemsetAsync(tensor_absmax, 0, 4, s), "hipMemsetAsync(tensor_absmax)");
   if (rc != DCQ_OK) return rc;
   const int64_t n = G * S;
-  const unsigned grid = small_grid(n / 8);
+  const uintptr_t width = storage == DCQ_F32 ? 4 : 2;
+  DCQ_REQUIRE(reinterpret_cast<uintptr_t>(x) % width == 0, DCQ_ERR_ARGUMENT, "x is not aligned to its element type");
+  int64_t head = static_cast<int64_t>(((16 - (reinterpret_cast<uintptr_t>(x) & 15u)) & 15u) / width);
+  if (head > n) head = n;
+  // two workgroups per compute unit, each lane with kAbsmaxLoads loads in flight (see the kernel)
+  const int64_t lane_loads = (n / (storage == DCQ_F32 ? 4 : 8) + kAbsmaxLoads - 1) / kAbsmaxLoads;
+  int64_t wanted = (lane_loads + kBlock - 1) / kBlock;
+  wanted = wanted < 1 ? 1 : (wanted > 512 ? 512 : wanted);
+  const unsigned grid = static_cast<unsigned>(wanted);
   switch (storage) {
     case DCQ_F32:
       hipLaunchKernelGGL(tensor_absmax_kernel<DCQ_F32>, dim3(grid), dim3(kBlock), 0, s, static_cast<const float*>(x), n,
-                         tensor_absmax);
+                         head, tensor_absmax, nonfinite);
       break;
     case DCQ_F16:
       hipLaunchKernelGGL(tensor_absmax_kernel<DCQ_F16>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint16_t*>(x), n,
-                         tensor_absmax);
+                         head, tensor_absmax, nonfinite);
       break;
     case DCQ_BF16:
       hipLaunchKernelGGL(tensor_absmax_kernel<DCQ_BF16>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint16_t*>(x),
-                         n, tensor_absmax);
+                         n, head, tensor_absmax, nonfinite);
       break;
     default:
       set_error("bad storage %d", storage);
@@ -715,7 +774,7 @@ int dcq_fake_quant_groups_two_level(const dcq_step* step, const dcq_rounding* le
   }
   DCQ_LAUNCH_CHECK("tensor_absmax_kernel launch");
   rc = try_launch_fused_table(*step, x, storage, G, S, has_ratio, ratio, tensor_absmax, level0, level0_span, dequant,
-                              codes, level0_out, level1_out, scale, nullptr, s);
+                              codes, level0_out, level1_out, scale, nullptr, s, nullptr);
   if (rc != DCQ_ERR_UNSUPPORTED) return rc;
   GroupParams p{};
   p.step = *step;
@@ -736,7 +795,7 @@ int dcq_fake_quant_groups_two_level(const dcq_step* step, const dcq_rounding* le
 }
 
 int dcq_group_range(const void* x, int32_t storage, int64_t G, int64_t S, int32_t zero_domain, const float* outer,
-                    float outer_lo, float outer_hi, float* vmax, float* vmin, dcq_stream_t stream) {
+                    float outer_lo, float outer_hi, float* vmax, float* vmin, int32_t* nonfinite, dcq_stream_t stream) {
   DCQ_REQUIRE(G >= 0 && S >= 0, DCQ_ERR_ARGUMENT, "negative size");
   if (G == 0 || S == 0) return DCQ_OK;
   DCQ_REQUIRE(x && vmax, DCQ_ERR_ARGUMENT, "NULL buffer");
@@ -753,6 +812,7 @@ int dcq_group_range(const void* x, int32_t storage, int64_t G, int64_t S, int32_
   p.outer_hi = outer_hi;
   p.vmax_out = vmax;
   p.vmin_out = vmin;
+  p.nonfinite = nonfinite;
   return dispatch_storage<kRangeOnly>(p, storage, storage, static_cast<hipStream_t>(stream));
 }
 
@@ -854,7 +914,7 @@ int dcq_zero_point(const dcq_step* step, int64_t n, const float* vmin, const flo
 int dcq_quantize_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S, const float* scale,
                         const float* zero, const float* outer, float outer_lo, float outer_hi, int32_t deq_clamp,
                         float deq_lo, float deq_hi, void* dequant, int32_t out_storage, float* codes,
-                        const float* round_delta, dcq_stream_t stream) {
+                        const float* round_delta, int32_t* nonfinite, dcq_stream_t stream) {
   int rc = validate_step(step);
   if (rc != DCQ_OK) return rc;
   DCQ_REQUIRE(G >= 0 && S >= 0, DCQ_ERR_ARGUMENT, "negative size");
@@ -880,6 +940,7 @@ int dcq_quantize_groups(const dcq_step* step, const void* x, int32_t storage, in
               "round_delta is defined for integer types only");
   DCQ_REQUIRE((reinterpret_cast<uintptr_t>(round_delta) & 15u) == 0, DCQ_ERR_ARGUMENT, "round_delta must be 16-byte aligned");
   p.round_delta = round_delta;
+  p.nonfinite = nonfinite;
   return dispatch_storage<kQuantOnly>(p, storage, dequant ? out_storage : storage, static_cast<hipStream_t>(stream));
 }
 

@@ -26,10 +26,80 @@ _ZD = {None: _lib.ZERO_NONE, ZeroPointDomain.PreScale: _lib.ZERO_PRE, ZeroPointD
 _TORCH_ROUND = {torch.float32: _lib.ROUND_F32, torch.float16: _lib.ROUND_F16, torch.bfloat16: _lib.ROUND_BF16}
 
 
-# When the quantizer checks its input for NaN / Inf (the reference asserts on the codes of every call,
-# quantizer/impl/base.py:250-251; here the check is one more read of the tensor and a host read):
-# "export" -- calls that return codes, "always", "never".
-FINITE_CHECKS: str = os.environ.get("DCQ_FINITE_CHECKS", "export")
+# When the quantizer refuses NaN / Inf (the reference asserts on the codes of every call,
+# quantizer/impl/base.py:250-251).  The kernels notice a NaN / Inf while they read the tensor anyway and set a device
+# flag (no extra pass); the policy says when the host looks at it:
+#   "always"   -- before ``quantize`` returns, as the reference (one blocking 4-byte read per call);
+#   "deferred" -- never by itself: the flag accumulates until ``raise_if_nonfinite()`` (pipelines that must not block
+#                 per call check once per layer or stage);
+#   "export"   -- like "always" for calls that return codes, like "deferred" for the others;
+#   "never"    -- the kernels are not even given the flag.
+FINITE_CHECKS: str = os.environ.get("DCQ_FINITE_CHECKS", "always")
+NONFINITE_SEEN = 4
+
+
+class _FiniteState(threading.local):
+    """Per host thread (pipelines on several HIP streams run one thread each): the flag word per device, and the flag
+    the kernels launched by this thread currently report into (None outside ``finite_scope``)."""
+
+    def __init__(self):
+        self.flags: dict[torch.device, torch.Tensor] = {}
+        self.armed: torch.Tensor | None = None
+
+
+_finite = _FiniteState()
+
+
+def _flag_of(device: torch.device) -> torch.Tensor:
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    flag = _finite.flags.get(device)
+    if flag is None:
+        flag = _finite.flags[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return flag
+
+
+class finite_scope:
+    """Kernels launched by this thread inside the scope report NaN / Inf inputs into the thread's flag word of
+    ``device`` (policy "never": no flag, nothing reported)."""
+
+    def __init__(self, device: torch.device):
+        self.flag = None if FINITE_CHECKS == "never" else _flag_of(device)
+
+    def __enter__(self):
+        self.previous, _finite.armed = _finite.armed, self.flag
+        return self
+
+    def __exit__(self, *exc):
+        _finite.armed = self.previous
+        return False
+
+
+def _nonfinite_ptr():
+    flag = _finite.armed
+    return None if flag is None else C.c_void_p(flag.data_ptr())
+
+
+def take_nonfinite(device: torch.device) -> int:
+    """Blocking read of the thread's flag word on ``device``; a set flag is cleared.  0: every tensor the armed
+    kernels have read since the last look was finite."""
+    flag = _finite.flags.get(torch.device(device))
+    if flag is None:
+        return 0
+    seen = int(flag.item())
+    if seen:
+        flag.zero_()
+    return seen
+
+
+def raise_if_nonfinite(device: torch.device | None = None) -> None:
+    """The deferred form of the reference's assertion: raises when a kernel armed by this thread has read a NaN or an
+    Inf since the last look (on ``device``, default: every device this thread has used)."""
+    devices = list(_finite.flags) if device is None else [torch.device(device)]
+    for dev in devices:
+        if take_nonfinite(dev):
+            raise AssertionError("Quantized tensor contains NaN or Inf (seen by the quantization kernels).")
 
 
 def _require_gpu(t: torch.Tensor) -> None:
@@ -143,7 +213,7 @@ def fake_quant_fused(step: Step, x: torch.Tensor, *, range_max=None, range_min=N
     scale, zero = _f32(G, x.device), _f32(G, x.device)
     check(lib().dcq_fake_quant_groups(C.byref(step), ptr(x), storage_of(x.dtype), G, S, ptr(range_max), ptr(range_min),
                                       int(ratio is not None), float(ratio or 0.0), ptr(dq), ptr(codes), ptr(scale),
-                                      ptr(zero), stream_of(x.device)), "dcq_fake_quant_groups")
+                                      ptr(zero), _nonfinite_ptr(), stream_of(x.device)), "dcq_fake_quant_groups")
     return dq, codes, scale, zero
 
 
@@ -162,7 +232,7 @@ def fake_quant_fused_outer(step: Step, x: torch.Tensor, outer: torch.Tensor, out
                                             float(outer_hi), int(deq_clamp), float(deq_lo), float(deq_hi),
                                             ptr(range_max), ptr(range_min), int(ratio is not None), float(ratio or 0.0),
                                             ptr(dq), storage_of(out_dtype), ptr(codes), ptr(scale), ptr(zero),
-                                            stream_of(x.device)), "dcq_fake_quant_groups_outer")
+                                            _nonfinite_ptr(), stream_of(x.device)), "dcq_fake_quant_groups_outer")
     return dq, codes, scale, zero
 
 
@@ -200,7 +270,7 @@ def fake_quant_progressive(first: Step, last: Step, x: torch.Tensor, group: int,
         C.byref(first), C.byref(last), ptr(x), storage_of(x.dtype), rows, row_len, group, int(first_ratio is not None),
         float(first_ratio or 0.0), int(ratio is not None), float(ratio or 0.0), float(outer_lo), float(outer_hi),
         int(deq_clamp), float(deq_lo), float(deq_hi), ptr(dq), ptr(codes), ptr(s0), ptr(scale), ptr(zero),
-        stream_of(x.device)), "dcq_fake_quant_progressive")
+        _nonfinite_ptr(), stream_of(x.device)), "dcq_fake_quant_progressive")
     return dq, codes, s0, scale, zero
 
 
@@ -216,7 +286,8 @@ def fake_quant_two_level(step: Step, level0: Rounding, level0_span: float, x: to
     check(lib().dcq_fake_quant_groups_two_level(C.byref(step), C.byref(level0), float(level0_span), ptr(x),
                                                 storage_of(x.dtype), G, S, int(ratio is not None), float(ratio or 0.0),
                                                 ptr(top), ptr(dq), ptr(codes), ptr(first), ptr(second), ptr(scale),
-                                                stream_of(x.device)), "dcq_fake_quant_groups_two_level")
+                                                _nonfinite_ptr(), stream_of(x.device)),
+          "dcq_fake_quant_groups_two_level")
     return dq, codes, first, second, scale
 
 
@@ -228,7 +299,7 @@ def group_range(x: torch.Tensor, *, with_min: bool, outer: torch.Tensor | None =
     vmin = _f32(G, x.device) if with_min else None
     zd = _lib.ZERO_POST if with_min else _lib.ZERO_NONE
     check(lib().dcq_group_range(ptr(x), storage_of(x.dtype), G, S, zd, ptr(outer), outer_lo, outer_hi, ptr(vmax),
-                                ptr(vmin), stream_of(x.device)), "dcq_group_range")
+                                ptr(vmin), _nonfinite_ptr(), stream_of(x.device)), "dcq_group_range")
     return vmax, vmin
 
 
@@ -341,8 +412,8 @@ def quantize_groups(step: Step, x: torch.Tensor, scale, zero, *, outer=None, out
     codes = torch.empty((G, S), dtype=torch.float32, device=x.device) if want_codes else None
     check(lib().dcq_quantize_groups(C.byref(step), ptr(x), storage_of(x.dtype), G, S, ptr(scale), ptr(zero), ptr(outer),
                                     outer_lo, outer_hi, int(deq_clamp), deq_lo, deq_hi, ptr(dq),
-                                    storage_of(out_dtype), ptr(codes), ptr(round_delta), stream_of(x.device)),
-          "dcq_quantize_groups")
+                                    storage_of(out_dtype), ptr(codes), ptr(round_delta), _nonfinite_ptr(),
+                                    stream_of(x.device)), "dcq_quantize_groups")
     return dq, codes
 
 
@@ -474,7 +545,8 @@ def smooth_fake_quant(step: Step, x: torch.Tensor, groups_per_row: int, chan_sca
     check(lib().dcq_smooth_fake_quant_groups(C.byref(step), ptr(x), storage_of(x.dtype), G, S, groups_per_row, ptr(cs), K,
                                              1 if divide_first else 0, 0 if ratio is None else 1,
                                              0.0 if ratio is None else float(ratio), ptr(out), ptr(errors), degree,
-                                             ptr(table), stream_of(x.device)), "dcq_smooth_fake_quant_groups")
+                                             ptr(table), _nonfinite_ptr(), stream_of(x.device)),
+          "dcq_smooth_fake_quant_groups")
     return out if errors is None else errors
 
 

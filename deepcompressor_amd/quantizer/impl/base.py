@@ -101,8 +101,20 @@ class QuantizerImpl:
             "dynamic_range must have one entry per step")
         if isinstance(kernel, BaseQuantKernelConfig):
             kernel = kernel.build()
-        if kernel is None or type(kernel) is QuantRtnKernel:
-            self._check_finite_input(tensor, scale, dynamic_range, return_with_quant)
+        native_rtn = kernel is None or type(kernel) is QuantRtnKernel
+        if not native_rtn:  # GPTQ / caller-supplied kernel objects: their codes are checked where they are made
+            return self._dispatch(tensor, kernel, scale, zero, dynamic_range, round_delta, return_with_dequant,
+                                  return_with_quant, kwargs)
+        # The kernels report a NaN / Inf in what they read into the thread's flag word; see _refuse_nonfinite
+        with engine.finite_scope(tensor.device):
+            result = self._dispatch(tensor, kernel, scale, zero, dynamic_range, round_delta, return_with_dequant,
+                                    return_with_quant, kwargs)
+        self._refuse_nonfinite(tensor, scale, dynamic_range, return_with_quant)
+        return result
+
+    def _dispatch(self, tensor, kernel, scale, zero, dynamic_range, round_delta, return_with_dequant,
+                  return_with_quant, kwargs) -> QuantTensor:
+        n_steps = self.info.num_steps
         if n_steps > 2:
             return self._quantize_chain(tensor, kernel, scale, zero, dynamic_range, round_delta, return_with_dequant,
                                         return_with_quant, kwargs)
@@ -124,22 +136,28 @@ class QuantizerImpl:
                                       return_with_quant, kwargs)
 
     @staticmethod
-    def _check_finite_input(tensor, scale, dynamic_range, want_quant: bool) -> None:
+    def _refuse_nonfinite(tensor, scale, dynamic_range, want_quant: bool) -> None:
         """The reference asserts that the codes hold neither NaN nor Inf (impl/base.py:250-251).  The round-to-nearest
         kernels here clamp with min / max instructions, which drop a NaN operand, so their codes cannot show it; the
-        condition is checked where it arises: a NaN anywhere in the input gives the reference NaN codes, and so does
-        an Inf when the step's range is taken from the data (Inf / Inf).  One extra read of the tensor and one host
-        read, so by default (``engine.FINITE_CHECKS == "export"``) only calls that hand back codes pay it;
-        ``"always"`` checks every call as the reference does, ``"never"`` none."""
+        condition is caught where it arises -- a NaN anywhere in the input gives the reference NaN codes, and so does
+        an Inf when the step's range is taken from the data (Inf / Inf) -- by the kernels themselves while they read
+        the tensor (no extra pass).  This is the host's look at their flag: one blocking 4-byte read, by default
+        before every return as the reference does (``engine.FINITE_CHECKS``: "always"; "export": only for calls that
+        hand back codes; "deferred": at ``engine.raise_if_nonfinite()``; "never")."""
         policy = engine.FINITE_CHECKS
-        if policy == "never" or (policy != "always" and not want_quant):
+        if policy in ("never", "deferred") or (policy == "export" and not want_quant):
             return
-        if bool(torch.isfinite(tensor).all()):
+        if not engine.take_nonfinite(tensor.device):
             return
+        # rare path: tell NaN from Inf as the reference's two assertions do
+        if policy != "always" and bool(torch.isfinite(tensor).all()):
+            # not this tensor: the flag was left by an earlier call of this thread that nobody has looked at yet
+            raise AssertionError("Quantized tensor contains NaN or Inf (a tensor quantized earlier on this thread, "
+                                 "whose check was deferred).")
         assert not tensor.isnan().any(), "Quantized tensor contains NaN."
         from_data = all(s is None for s in scale) and all(
             d is None or (d.max is None and not isinstance(d.ratio, torch.Tensor)) for d in dynamic_range)
-        if from_data:
+        if from_data and bool(tensor.isinf().any()):
             raise AssertionError("Quantized tensor contains NaN.")  # the reference's Inf / Inf
 
     # ---- fused path --------------------------------------------------------------------------

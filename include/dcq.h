@@ -101,10 +101,18 @@ int dcq_round_to_codebook(const void* x, void* y, int64_t n, int32_t storage, co
  *   dequant             : optional output, `storage` type, same layout as x.
  *   codes               : optional output, float32 integer/codebook values (the reference's qdata).
  *   scale, zero         : optional outputs [G] float32 (zero is all 0 without a zero point).
+ *   nonfinite           : optional device int32, |= 4 (DCQ_NONFINITE_SEEN) when an element of x is NaN or +-Inf --
+ *                         the reference's `assert not tensor.isnan().any()` / `.isinf().any()` on every call
+ *                         (quantizer/impl/base.py:250-251), detected while the tensor is read anyway: the codes of
+ *                         these kernels are clamped with min / max instructions and cannot show a NaN themselves.
+ *                         The caller zeroes it and reads it when it wants to know.  Every entry point below that
+ *                         takes `nonfinite` treats it this way.
  * ------------------------------------------------------------------------------------------- */
+#define DCQ_NONFINITE_SEEN 4
 int dcq_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
                           const float* range_max, const float* range_min, int32_t has_ratio, float ratio,
-                          void* dequant, float* codes, float* scale, float* zero, dcq_stream_t stream);
+                          void* dequant, float* codes, float* scale, float* zero, int32_t* nonfinite,
+                          dcq_stream_t stream);
 
 /* dcq_fake_quant_groups_outer: the LAST step of a progressive (two-step) quantizer in one pass, e.g. the uint4 g128
  * step of QoQ on top of its per-channel sint8 step (quantizer/impl/base.py:211-279): the group's data is
@@ -116,7 +124,7 @@ int dcq_fake_quant_groups_outer(const dcq_step* step, const void* x, int32_t sto
                                 const float* outer, float outer_lo, float outer_hi, int32_t deq_clamp, float deq_lo,
                                 float deq_hi, const float* range_max, const float* range_min, int32_t has_ratio,
                                 float ratio, void* dequant, int32_t out_storage, float* codes, float* scale, float* zero,
-                                dcq_stream_t stream);
+                                int32_t* nonfinite, dcq_stream_t stream);
 
 /* dcq_fake_quant_progressive: BOTH steps of a two-step progressive quantizer in one pass over x[rows][row_len] when
  * the first step has one group per row, no zero point and a float scale (QoQ W4: per-channel sint8 with fp16 scales,
@@ -130,7 +138,7 @@ int dcq_fake_quant_progressive(const dcq_step* first, const dcq_step* last, cons
                                int64_t rows, int64_t row_len, int64_t S, int32_t first_has_ratio, float first_ratio,
                                int32_t has_ratio, float ratio, float outer_lo, float outer_hi, int32_t deq_clamp,
                                float deq_lo, float deq_hi, void* dequant, float* codes, float* first_scale,
-                               float* scale, float* zero, dcq_stream_t stream);
+                               float* scale, float* zero, int32_t* nonfinite, dcq_stream_t stream);
 
 /* dcq_fake_quant_groups_two_level: fake quantization with TWO scale levels, the first one per tensor -- NVFP4:
  * float4 codes in groups of 16 with float8 group scales relative to one 16-bit scale of the whole tensor
@@ -142,7 +150,7 @@ int dcq_fake_quant_progressive(const dcq_step* first, const dcq_step* last, cons
 int dcq_fake_quant_groups_two_level(const dcq_step* step, const dcq_rounding* level0, float level0_span, const void* x,
                                     int32_t storage, int64_t G, int64_t S, int32_t has_ratio, float ratio,
                                     float* tensor_absmax, void* dequant, float* codes, float* level0_out,
-                                    float* level1_out, float* scale, dcq_stream_t stream);
+                                    float* level1_out, float* scale, int32_t* nonfinite, dcq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Building blocks of the general path (multi-level scales, progressive two-step configs, custom
@@ -154,7 +162,7 @@ int dcq_fake_quant_groups_two_level(const dcq_step* step, const dcq_rounding* le
  * progressive step (quantizer/impl/base.py:221-224).  data/range.py:309-322. */
 int dcq_group_range(const void* x, int32_t storage, int64_t G, int64_t S, int32_t zero_domain,
                     const float* outer, float outer_lo, float outer_hi, float* vmax, float* vmin,
-                    dcq_stream_t stream);
+                    int32_t* nonfinite, dcq_stream_t stream);
 
 /* ratio, PreScale clamp, static bound, RangeBound, span / q_span -> un-quantized linear scale [n];
  * vmin is updated in place to the range minimum the zero point must use.  `vavg` (NULL, or the group
@@ -192,7 +200,7 @@ int dcq_zero_point(const dcq_step* step, int64_t n, const float* vmin, const flo
 int dcq_quantize_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
                         const float* scale, const float* zero, const float* outer, float outer_lo, float outer_hi,
                         int32_t deq_clamp, float deq_lo, float deq_hi, void* dequant, int32_t out_storage,
-                        float* codes, const float* round_delta, dcq_stream_t stream);
+                        float* codes, const float* round_delta, int32_t* nonfinite, dcq_stream_t stream);
 
 /* out[g][i] = clamp(x[g][i] / outer[g], lo, hi) in float32: the working tensor a progressive step hands to the next
  * one (quantizer/impl/base.py:221-224); only needed when a caller-supplied kernel object must see that tensor. */
@@ -248,9 +256,10 @@ int dcq_product_error(const void* y, const void* y0, int32_t storage, int64_t G,
 
 /* Self-test hook (no reference counterpart): evaluates the kernels' division-by-group-scale routine
  * (fast[i]; used_fast[i] says whether the reciprocal path or the plain division was taken) next to the
- * hardware's IEEE division (ref[i]) for n pairs (x[i], s[i]), so a test can assert bitwise equality. */
-int dcq_selftest_division(const float* x, const float* s, float* fast, float* ref, int32_t* used_fast, int64_t n,
-                          dcq_stream_t stream);
+ * hardware's IEEE division (ref[i]) for n pairs (x[i], s[i]), so a test can assert bitwise equality.
+ * one_step (optional): the one-correction form the kernels use for divisors of at most 16 significant bits. */
+int dcq_selftest_division(const float* x, const float* s, float* fast, float* ref, int32_t* used_fast,
+                          float* one_step, int64_t n, dcq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GPTQ (deepcompressor/quantizer/kernel/gptq.py:128-285).
@@ -407,7 +416,7 @@ int dcq_gemm_f64(const void* A, int32_t a_storage, int64_t lda, int32_t a_kmajor
 int dcq_smooth_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
                                  int64_t groups_per_row, const float* chan_scale, int32_t K, int32_t mode,
                                  int32_t has_ratio, float ratio, void* dequant, float* errors, double degree,
-                                 const uint16_t* pow_table, dcq_stream_t stream);
+                                 const uint16_t* pow_table, int32_t* nonfinite, dcq_stream_t stream);
 
 int dcq_channel_metric(const void* x, int32_t storage, int64_t N, int64_t C, int64_t inner, int32_t mode, float* out_max,
                        double* out_sum, dcq_stream_t stream);

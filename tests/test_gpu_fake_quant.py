@@ -92,28 +92,63 @@ def test_empty_and_cpu_inputs_fail_loudly():
         q.quantize(torch.zeros(4, 128, dtype=torch.bfloat16))
 
 
-@pytest.mark.parametrize("cname", ["uint4_post_g128_f16s", "nvfp4_g16", "qoq_g128"])
-def test_nan_and_inf_inputs_are_refused_like_the_reference(cname, monkeypatch):
-    """The reference asserts 'Quantized tensor contains NaN / Inf' on the codes (impl/base.py:250-251): a NaN input
-    always ends there, an Inf input when the range comes from the data (Inf / Inf).  Calls that return codes check by
-    default, every call under the "always" policy, none under "never"."""
+@pytest.mark.parametrize("cname", sorted(FQ.meta["cases"]))  # every kernel route: fused, chunked, table, progressive,
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])  # multi-level, permuted groups
+def test_nan_and_inf_inputs_are_refused_like_the_reference(cname, dtype, monkeypatch):
+    """The reference asserts 'Quantized tensor contains NaN / Inf' on the codes of every call (impl/base.py:250-251):
+    a NaN input always ends there, an Inf input when the range comes from the data (Inf / Inf).  The kernels notice
+    either while they read the tensor; by default every call looks at their flag before it returns."""
     from deepcompressor_amd import engine
-    q = build_quantizer(FQ.meta["cases"][cname])
+    assert engine.FINITE_CHECKS == "always"  # the default is the reference's behaviour
+    case = FQ.meta["cases"][cname]
+    q = build_quantizer(case)
     g = torch.Generator().manual_seed(9)
-    w = (torch.randn(32, 512, generator=g) * 0.05).to(torch.bfloat16).cuda()
-    for bad in (float("nan"), float("inf")):
+    w = (torch.randn(32, 512, generator=g) * 0.05).to(dtype).cuda()
+    if "conv" in cname:
+        w = w.view(32, 32, 4, 4)
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        for spot in ((5, 77), (5, 78), (31, 511), (0, 0)):  # both halves of a packed word, first and last element
+            wb = w.clone()
+            wb.view(32, 512)[spot] = bad
+            with pytest.raises(AssertionError, match="Quantized tensor contains"):
+                q.quantize(wb)
+            with pytest.raises(AssertionError, match="Quantized tensor contains"):
+                q.quantize(wb, return_with_dequant=False, return_with_quant=True)
+            q.quantize(w)  # the flag was cleared: a finite tensor passes again
         wb = w.clone()
-        wb[5, 77] = bad
+        wb.view(32, 512)[5, 77] = bad
+        monkeypatch.setattr(engine, "FINITE_CHECKS", "export")
+        q.quantize(wb)  # dequantized values only: not looked at under "export" ...
         with pytest.raises(AssertionError, match="Quantized tensor contains"):
-            q.quantize(wb, return_with_dequant=False, return_with_quant=True)
-        q.quantize(wb)  # dequantized values only: unchecked by default
-        monkeypatch.setattr(engine, "FINITE_CHECKS", "always")
-        with pytest.raises(AssertionError, match="Quantized tensor contains"):
-            q.quantize(wb)
+            q.quantize(w, return_with_dequant=False, return_with_quant=True)  # ... the flag stays until someone looks
+        monkeypatch.setattr(engine, "FINITE_CHECKS", "deferred")
+        q.quantize(wb)
+        q.quantize(w)
+        with pytest.raises(AssertionError, match="NaN or Inf"):
+            engine.raise_if_nonfinite()
+        engine.raise_if_nonfinite()  # cleared
         monkeypatch.setattr(engine, "FINITE_CHECKS", "never")
         q.quantize(wb, return_with_dequant=False, return_with_quant=True)
-        monkeypatch.setattr(engine, "FINITE_CHECKS", "export")
+        monkeypatch.setattr(engine, "FINITE_CHECKS", "always")
     q.quantize(w, return_with_dequant=False, return_with_quant=True)
+
+
+def test_inf_with_a_given_range_is_clamped_as_in_the_reference():
+    """With a static range the reference's codes of an Inf are the clamped ends (no assertion fires); NaN still
+    raises."""
+    from deepcompressor_amd.data.range import DynamicRange
+    q = build_quantizer(FQ.meta["cases"]["uint4_post_g128_f16s"])
+    g = torch.Generator().manual_seed(10)
+    w = (torch.randn(16, 256, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    rng = DynamicRange(max=w.float().view(16, 1, 2, 128).amax(dim=3, keepdim=True),
+                       min=w.float().view(16, 1, 2, 128).amin(dim=3, keepdim=True))
+    wb = w.clone()
+    wb[3, 9], wb[4, 200] = float("inf"), float("-inf")
+    codes = q.quantize(wb, dynamic_range=rng, return_with_dequant=False, return_with_quant=True).qdata
+    assert codes[3, 9] == 15 and codes[4, 200] == 0
+    wb[7, 7] = float("nan")
+    with pytest.raises(AssertionError, match="contains NaN"):
+        q.quantize(wb, dynamic_range=rng)
 
 
 def test_codebook_round_matches_oracle():
@@ -154,11 +189,52 @@ def test_division_by_group_scale_is_ieee_exact():
     fast, ref = torch.empty_like(xd), torch.empty_like(xd)
     used = torch.empty(n, dtype=torch.int32, device="cuda")
     _lib.check(_lib.lib().dcq_selftest_division(_lib.ptr(xd), _lib.ptr(sd), _lib.ptr(fast), _lib.ptr(ref),
-                                                _lib.ptr(used), n, _lib.stream_of(xd.device)), "selftest")
+                                                _lib.ptr(used), None, n, _lib.stream_of(xd.device)), "selftest")
     same = (fast.view(torch.int32) == ref.view(torch.int32))
     tiny = (xd.abs() < 2.0 ** -96) & (used == 1)  # documented exemption: |x/s| < 2^-36, rounding-irrelevant
     assert bool((same | tiny).all()), f"{int((~(same | tiny)).sum())} quotients differ from IEEE division"
     assert bool(((fast - ref).abs()[tiny] <= ref.abs()[tiny] * 1e-6 + 1e-44).all())
+    assert int(used.sum()) > n * 0.9
+    assert torch.equal(ref.cpu(), x / s)
+
+
+@pytest.mark.parametrize("kind", ["f16", "bf16", "int8", "fp8_x_f16"])
+def test_one_step_division_by_a_short_scale_is_ieee_exact(kind):
+    """Scales whose significand has at most 16 bits (rounded to a 16-bit float, an integer of up to 8 bits, a float8
+    level times a float16 level) take a division with ONE correction step; it must equal the IEEE quotient bit for bit
+    for any float32 numerator: random ones, ones built to land on or next to the half-way points between two
+    float32 quotients, and ones next to the k + 0.5 boundaries of the integer rounding that follows."""
+    from deepcompressor_amd import _lib
+    g = torch.Generator().manual_seed(hash(kind) % 1000)
+    n = 1 << 24
+    if kind == "f16":
+        s = torch.exp2(torch.rand(n, generator=g) * 40 - 30).to(torch.float16).float().clamp_min(2.0 ** -24)
+    elif kind == "bf16":
+        s = torch.exp2(torch.rand(n, generator=g) * 60 - 40).to(torch.bfloat16).float()
+    elif kind == "int8":
+        s = torch.randint(1, 256, (n,), generator=g).float()
+    else:  # e4m3 values (4 significant bits) times float16 values (11)
+        a = (1 + torch.randint(0, 8, (n,), generator=g).float() / 8) * torch.exp2(torch.randint(-6, 9, (n,), generator=g).float())
+        s = a * torch.exp2(torch.rand(n, generator=g) * 20 - 14).to(torch.float16).float()
+    assert int(((s.view(torch.int32) & 0xFF) != 0).sum()) == 0  # at most 16 significant bits
+    x = torch.randn(n, generator=g) * torch.exp2(torch.randint(-20, 8, (n,), generator=g).float())
+    q = n // 4
+    # quotients at / next to half-way points of float32: x = RN(s * m) for m with 25 significant bits
+    base = torch.randn(q, generator=g).abs() + 0.5
+    mid = (base.double() + (torch.rand(q, generator=g) < 2).double() * (torch.nextafter(base, torch.full((q,), 9.0)) - base).double() / 2)
+    x[:q] = (mid * s[:q].double()).float()
+    x[q: 2 * q] = torch.nextafter(x[:q], torch.full((q,), 1e30))
+    # next to the k + 0.5 boundaries of the rounding to integer codes
+    k = torch.randint(-128, 128, (q,), generator=g).float() + 0.5
+    x[2 * q: 3 * q] = torch.nextafter(k * s[2 * q: 3 * q], torch.where(torch.rand(q, generator=g) < 0.5, -1e30, 1e30))
+    xd, sd = x.cuda(), s.cuda()
+    fast, ref, one = torch.empty_like(xd), torch.empty_like(xd), torch.empty_like(xd)
+    used = torch.empty(n, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().dcq_selftest_division(_lib.ptr(xd), _lib.ptr(sd), _lib.ptr(fast), _lib.ptr(ref),
+                                                _lib.ptr(used), _lib.ptr(one), n, _lib.stream_of(xd.device)), "selftest")
+    same = one.view(torch.int32) == ref.view(torch.int32)
+    tiny = (xd.abs() < 2.0 ** -96) & (used == 1)
+    assert bool((same | tiny).all()), f"{int((~(same | tiny)).sum())} quotients differ from IEEE division"
     assert int(used.sum()) > n * 0.9
     assert torch.equal(ref.cpu(), x / s)
 

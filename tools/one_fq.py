@@ -18,5 +18,5 @@ x2d, _ = engine.canonical_groups(w, info.steps[0].tensor_view_shape)
 G, S = x2d.shape
 dq = torch.empty_like(x2d); sc = torch.empty(G, device="cuda"); ze = torch.empty(G, device="cuda")
 for _ in range(4):
-    lib().dcq_fake_quant_groups(C.byref(step), ptr(x2d), storage_of(dt), G, S, None, None, 0, 0.0, ptr(dq), None, ptr(sc), ptr(ze), stream_of(w.device))
+    lib().dcq_fake_quant_groups(C.byref(step), ptr(x2d), storage_of(dt), G, S, None, None, 0, 0.0, ptr(dq), None, ptr(sc), ptr(ze), None, stream_of(w.device))
 torch.cuda.synchronize()
