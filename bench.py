@@ -133,8 +133,10 @@ def quantize_layer(weights, caches, config, syrk_events=None, streams: int = 1, 
     return [e.module for e in entries]
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r2_stage_pmc.json")
-SYRK_PMC_FILE = os.path.join(ROOT, "profiles", "r2_syrk_traffic.json")
+PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_stage_pmc.json") for r in (3, 2)) if os.path.exists(p)),
+                os.path.join(ROOT, "profiles", "r3_stage_pmc.json"))
+SYRK_PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_syrk_traffic.json") for r in (3, 2))
+                      if os.path.exists(p)), os.path.join(ROOT, "profiles", "r3_syrk_traffic.json"))
 VALU_ISSUE_PER_S = 256 * 4 * 2.4e9 / 2  # wave-instructions: 4 SIMDs per CU, a wave64 instruction takes 2 cycles
 
 
@@ -156,8 +158,12 @@ def stage_rooflines(device, weights, objs) -> list:
       the per-group outputs, and the fraction of the chip's vector-instruction issue rate, from the instruction count
       of the committed counter pass (SQ_INSTS_VALU per launch) over the duration measured here.
 
-    Durations are HIP events on the launching stream around back-to-back calls (the kernels outlast the host's
-    per-call work)."""
+    Durations are HIP events on the launching stream around back-to-back ``quantize()`` calls (the kernels outlast
+    the host's per-call work).  The kernels detect NaN / Inf while they read; in these loops the host's look at their
+    flag -- by default a blocking 4-byte read before every return, as the reference asserts on every call -- is made
+    once after the timed calls (``engine.FINITE_CHECKS = "deferred"``), so that launches queue back to back and the
+    figure is the kernels' rate; ``default_policy_ms`` is the same call with the blocking look per call."""
+    from deepcompressor_amd import engine
     from deepcompressor_amd.calib import calibrate_dynamic_range
     from deepcompressor_amd.data.common import TensorType
     import torch.nn as nn
@@ -165,26 +171,33 @@ def stage_rooflines(device, weights, objs) -> list:
     Quantizer, qcfg, rcfg, _ = objs
     q = Quantizer(qcfg, key="rate", develop_dtype=torch.float32)
 
-    def timed(fn, reps):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+    def timed(fn, reps, policy="deferred"):
+        before, engine.FINITE_CHECKS = engine.FINITE_CHECKS, policy
+        try:
             fn()
-        e1.record()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            engine.raise_if_nonfinite()
+        finally:
+            engine.FINITE_CHECKS = before
         return e0.elapsed_time(e1) / reps * 1e-3
 
     out = []
     big = (torch.randn(32768, 8192, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
-    t_big = timed(lambda: q.quantize(big), 10)
+    t_big = timed(lambda: q.quantize(big), 30)
+    t_big_default = timed(lambda: q.quantize(big), 10, policy="always")
     big_bytes = big.numel() * 4 + (big.numel() // 128) * 8  # bf16 read + bf16 write, float32 scale + zero per group
     pmc = _pmc("fused_int_kernel")
     out.append({"kernel": "fused_int_kernel (fake-quant uint4 g128 + zero point, bf16 in / bf16 out)", "bound": "hbm",
                 "shape": list(big.shape), "achieved": big_bytes / t_big / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": big_bytes / t_big / 8e12, "frac_of_measured_copy_6290": big_bytes / t_big / 6.29e12,
                 "algorithmic_bytes": big_bytes, "traffic": pmc.get("hbm_bytes"), "avg_launch_ms": t_big * 1e3,
+                "default_policy_ms": t_big_default * 1e3,
                 "valu_insts_per_launch": pmc.get("avg_per_launch", {}).get("SQ_INSTS_VALU")})
     # The other two weight formats of the reference's examples, same tensor: NVFP4 (float4 in groups of 16, float8
     # group scales under one per-tensor scale: a max|x| reduction, then one pass) and QoQ W4 (per-row fp16 scales,
@@ -207,24 +220,26 @@ def stage_rooflines(device, weights, objs) -> list:
              nvfp4, n_big * 6 + (n_big // 16) * 8, ("tensor_absmax_kernel", "fused_table_kernel")),
             ("progressive_int_kernel (QoQ W4 g128: per-row fp16 scale and uint4 groups with integer scales, one pass)",
              qoq, n_big * 4 + (n_big // 128) * 8 + big.shape[0] * 4, ("progressive_int_kernel",))):
-        t = timed(lambda: quantizer.quantize(big), 10)
+        t = timed(lambda: quantizer.quantize(big), 30)
+        t_default = timed(lambda: quantizer.quantize(big), 10, policy="always")
         counted = [_pmc(k).get("hbm_bytes") for k in kernels]
         out.append({"kernel": label, "bound": "hbm", "shape": list(big.shape), "achieved": nbytes / t / 1e9,
                     "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 8e12, "algorithmic_bytes": nbytes,
                     "traffic": sum(counted) if all(c is not None for c in counted) else None,
-                    "avg_launch_ms": t * 1e3,
+                    "avg_launch_ms": t * 1e3, "default_policy_ms": t_default * 1e3,
                     "valu_insts_per_launch": sum(_pmc(k).get("avg_per_launch", {}).get("SQ_INSTS_VALU") or 0
                                                  for k in kernels) or None,
                     "note": "duration of the whole quantize() call (all its launches)"})
     del big
     w = weights["gate_proj"]
-    t_fq = timed(lambda: q.quantize(w), 20)
+    t_fq = timed(lambda: q.quantize(w), 50)
+    t_fq_default = timed(lambda: q.quantize(w), 20, policy="always")
     n = w.numel()
     fq_bytes = n * 4 + (n // 128) * 8
     out.append({"kernel": "fused_int_kernel on gate_proj (235 MB working set: Infinity-Cache resident when repeated)",
                 "bound": "hbm", "shape": list(w.shape), "achieved": fq_bytes / t_fq / 1e9, "peak": 8000.0,
                 "unit": "GB/s", "frac": fq_bytes / t_fq / 8e12, "algorithmic_bytes": fq_bytes, "traffic": None,
-                "avg_launch_ms": t_fq * 1e3})
+                "avg_launch_ms": t_fq * 1e3, "default_policy_ms": t_fq_default * 1e3})
     t_rs = timed(lambda: calibrate_dynamic_range(TensorType.Weights, rcfg, True, q, modules=[None], activations=None,
                                                  weights=[nn.Parameter(w, requires_grad=False)]), 3)
     rs_bytes = n * 2 + (n // 128) * 16  # bf16 read once; max, min, ratio, error per group
@@ -306,9 +321,18 @@ def other_configs(device) -> list:
         scale_dtypes=(torch.float16, QuantDataType.from_str("sint8")),
         intermediate_dtypes=(QuantDataType.from_str("sint8"),), intermediate_levels=(0,)), key="c2")
     layer = [(rand(r, c) * 0.02).to(torch.float16) for _, r, c, _ in LLAMA3_8B_LAYER]
+    from deepcompressor_amd import engine
+
     t = wall(lambda: [qoq.quantize(x) for x in layer], 5)
+    engine.FINITE_CHECKS = "deferred"  # the NaN / Inf flag looked at once per layer instead of once per linear
+    try:
+        t_deferred = wall(lambda: ([qoq.quantize(x) for x in layer], engine.raise_if_nonfinite()), 5)
+    finally:
+        engine.FINITE_CHECKS = "always"
     out.append({"config": "configs[2]: QoQ W4 progressive fake-quant of the 7 linears of one Llama-3-8B layer, fp16",
-                "ms": t * 1e3, "Gparam_per_s": PARAMS_PER_LAYER / t / 1e9})
+                "ms": t * 1e3, "Gparam_per_s": PARAMS_PER_LAYER / t / 1e9,
+                "ms_with_one_nonfinite_check_per_layer": t_deferred * 1e3,
+                "Gparam_per_s_with_one_check_per_layer": PARAMS_PER_LAYER / t_deferred / 1e9})
     del layer
     # configs[3]: SVDQuant W4 (sint4 g64) with a rank-32 low-rank branch on a FLUX.1-dev 3072 x 3072 linear
     svd = Quantizer(QuantizerConfig(dtype=QDType.sint4, zero_point=None, group_shapes=((1, 64),),

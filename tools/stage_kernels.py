@@ -17,6 +17,9 @@ import bench  # noqa: E402
 from deepcompressor_amd.calib import calibrate_dynamic_range  # noqa: E402
 from deepcompressor_amd.data.common import TensorType  # noqa: E402
 
+from deepcompressor_amd import engine  # noqa: E402
+
+engine.FINITE_CHECKS = "deferred"  # launches back to back; the flag is looked at once at the end
 dev = torch.device("cuda", 0)
 Quantizer, qcfg, rcfg, _ = bench.build_objects()
 q = Quantizer(qcfg, key="rate", develop_dtype=torch.float32)
@@ -45,4 +48,5 @@ for _ in range(3):
     calibrate_dynamic_range(TensorType.Weights, rcfg, True, q, modules=[None], activations=None,
                             weights=[nn.Parameter(w, requires_grad=False)])
 torch.cuda.synchronize()
+engine.raise_if_nonfinite()
 print("done")
