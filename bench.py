@@ -121,12 +121,11 @@ def quantize_layer(weights, caches, config, syrk_events=None, streams: int = 1, 
         layer_cache[f"layer.{name}"] = IOTensorsCache(inputs=TensorsCache(caches[key]))
 
     def hessian_hook(channels):
-        if syrk_events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            # torch creates the HIP event lazily on first record; record once so the handles exist
-            e0.record(), e1.record()
-            _lib.lib().dcq_profile_next_hessian(e0.cuda_event, e1.cuda_event)
-            syrk_events.append((e0, e1, channels))
+        if syrk_events is None:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        syrk_events.append((e0, e1, channels))
+        return e0, e1  # recorded by the library right around this Hessian's SYRK launches, on their stream
 
     quantize_layer_weights(entries, config, {}, layer_cache=layer_cache, streams=streams, hessian_hook=hessian_hook,
                            world=world, rank=rank)
@@ -550,10 +549,8 @@ def main() -> None:
                 continue
             seen.add(key)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(), e1.record()
-            _lib.lib().dcq_profile_next_hessian(e0.cuda_event, e1.cuda_event)
             alone_events.append((e0, e1, c))
-            gptq_mod.prepare_hessians([caches[key]], device)
+            gptq_mod.prepare_hessians([caches[key]], device, profile_events=(e0, e1))
         torch.cuda.synchronize()
         gptq_mod.clear_hessian_cache()
 

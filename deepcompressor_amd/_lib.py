@@ -70,6 +70,7 @@ _SIGNATURES = {
     "dcq_dequantize_groups": [C.POINTER(Step), _p, _i64, _i64, _p, _p, _p, _i32, _f, _f, _p, _i32, _p],
     "dcq_pow_table": [_i32, _d, _p, _p],
     "dcq_hessian_accumulate": [_p, _i32, _i64, _i64, _f, _p, _p, _i64, _p],
+    "dcq_hessian_accumulate_ex": [_p, _i32, _i64, _i64, _f, _p, _p, _i64, _i32, _p, _p, _p],
     "dcq_gptq_sweep_block": [C.POINTER(Step), _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _f, _i32, _i32, _i32, _p,
                              _p, _p, _i64, _p],
     "dcq_gptq_sweep": [C.POINTER(Step), _p, _i64, _i64, _i64, _p, _p, _p, _f, _i32, _i32, _i32, _p, _p, _p, _i32, _p],
@@ -116,10 +117,6 @@ def lib():
         handle.dcq_hessian_workspace_bytes.restype = C.c_int64
         handle.dcq_cholesky_workspace_bytes.argtypes = [_i64]
         handle.dcq_cholesky_workspace_bytes.restype = C.c_int64
-        handle.dcq_profile_next_hessian.argtypes = [_p, _p]
-        handle.dcq_profile_next_hessian.restype = None
-        handle.dcq_hessian_round_width.argtypes = [_i32]
-        handle.dcq_hessian_round_width.restype = None
         handle.dcq_version.restype = C.c_char_p
         handle.dcq_last_error.restype = C.c_char_p
         _lib = handle

@@ -175,7 +175,7 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
                            quantizer_state_dict: dict[str, tp.Any],
                            layer_cache: dict[str, IOTensorsCache] | None = None,
                            return_with_scale_state_dict: bool = False, develop_dtype: torch.dtype = torch.float32,
-                           streams: int = 1, hessian_hook: tp.Callable[[int], None] | None = None,
+                           streams: int = 1, hessian_hook: tp.Callable[[int], tp.Any] | None = None,
                            world: int = 1, rank: int = 0) -> dict[str, torch.Tensor | float | None]:
     """app/llm/quant/weight.py:24-105.  Pass 1 calibrates the range of every linear that has no entry in
     ``quantizer_state_dict`` yet (and stores it there); pass 2 reloads each range, quantizes the weight with the
@@ -186,7 +186,8 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
     the cached inputs they share (q/k/v, gate/up ...); the groups' Hessians are computed one after the other on the
     caller's stream, each with the whole chip, largest pipeline first, and every group's searches, inverse factor and
     sweeps start on a stream of their own as soon as that group's Hessian is there.  ``hessian_hook(channels)`` is
-    called right before each of those Hessians is enqueued (a measurement hook).
+    called right before each of those Hessians is enqueued (a measurement hook); it may return a pair of
+    ``torch.cuda.Event(enable_timing=True)``, which are then recorded around that Hessian's matrix-core launches.
 
     ``world`` > 1 (no counterpart in the reference either): ONE layer split over the ``world`` processes of the default
     process group, one per GPU.  Every rank passes the same modules (full weights) and the cache of ITS share of the
@@ -244,9 +245,8 @@ def _quantize_layer_weights_row_sharded(entries, config, quantizer_state_dict, l
                     seen.add(key)
                     caches.append((e.module.in_features, cache))
             for channels, cache in caches:
-                if hessian_hook is not None:
-                    hessian_hook(channels)
-                gptq_mod.prepare_hessians([cache], device, world=world)
+                events = hessian_hook(channels) if hessian_hook is not None else None
+                gptq_mod.prepare_hessians([cache], device, world=world, profile_events=events)
         for e, w, b in zip(entries, full, bounds):
             begin, end = b[rank]
             e.module.weight.data = w[begin:end]  # a contiguous view of whole rows
@@ -288,10 +288,9 @@ def _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, la
     # the compute units alone (measured: 120-122 -> 118-119 ms per Llama-3-8B layer; 3/4 and 15/16 gain less).
     width = torch.cuda.get_device_properties(device).multi_processor_count * 7 // 8
     for n, members in enumerate(order):
-        if hessian_hook is not None:
-            hessian_hook(members[0].module.in_features)
+        events = hessian_hook(members[0].module.in_features) if hessian_hook is not None else None
         gptq_mod.prepare_hessians([layer_cache[members[0].name].inputs.front()], device,
-                                  round_width=width if n > 0 else 0)
+                                  round_width=width if n > 0 else 0, profile_events=events)
         ready.append(torch.cuda.Event())
         ready[-1].record()
     # longest pipeline first, the rest dealt to the least loaded stream (each list ascending = order of readiness)

@@ -272,6 +272,9 @@ def convert_to_nunchaku_w8x8y16_linear_weight(weight: torch.Tensor, scale: torch
 def _scale_entry(scale: torch.Tensor, weight_ndim: int) -> tuple[torch.Tensor, str]:
     """A multi-element scale of a linear (or pointwise convolution) weight as [out][1][groups][1], and the engine's
     name for it: ``wcscales`` per output channel, ``wscales`` per group."""
+    if scale.ndim > 2 * weight_ndim and scale.shape[2 * weight_ndim:].numel() == 1:
+        # the quantizer's scale of a pointwise convolution weight: one more (1, 1) pair per kernel dimension
+        scale = scale.view(scale.shape[:2 * weight_ndim])
     assert scale.ndim == 2 * weight_ndim, "one (count, size) pair of dimensions per weight dimension"
     rows, groups = scale.shape[0], scale.shape[2]
     assert scale.numel() == rows * groups, "scales vary along output channels and input groups only"
@@ -290,10 +293,10 @@ def convert_to_nunchaku_w4x4y16_linear_state_dict(weight: torch.Tensor, scale: t
     Before packing, the low-rank down projection is taken back to un-smoothed inputs (divided by ``smooth`` unless the
     smoothing is fused into the previous layer), and a constant input ``shift`` contributes ``up @ down @ shift``
     through the branch, which joins the bias (both in float64)."""
-    weight_ndim = weight.ndim
-    if weight_ndim > 2:  # pointwise convolution: trailing dimensions of size 1
+    if weight.ndim > 2:  # pointwise convolution: trailing dimensions of size 1
         assert weight.numel() == weight.shape[0] * weight.shape[1]
         weight = weight.view(weight.shape[0], weight.shape[1])
+    weight_ndim = weight.ndim  # of the flattened weight, as the reference checks it (convert.py:24-30, 37)
     scale_key = "wtscale"
     if scale.numel() > 1:
         scale, scale_key = _scale_entry(scale, weight_ndim)

@@ -465,8 +465,6 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkParams p) {
   }
 }
 
-static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
-static thread_local int g_round_width = 0;  // workgroups per SYRK round asked for by this thread (0: one per compute unit)
 
 static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
@@ -887,13 +885,6 @@ int dcq_debug_read_stamps(unsigned long long* out) {
 }
 #endif
 
-void dcq_hessian_round_width(int32_t workgroups) { g_round_width = workgroups > 0 ? workgroups : 0; }
-
-void dcq_profile_next_hessian(void* start, void* stop) {
-  g_prof_start = static_cast<hipEvent_t>(start);
-  g_prof_stop = static_cast<hipEvent_t>(stop);
-}
-
 int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C) {
   if (T <= 0 || C <= 0) return 0;
   const HessianPlan h = plan_hessian(T, C);
@@ -902,6 +893,13 @@ int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C) {
 
 int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C, float alpha, float* H, void* workspace,
                            int64_t workspace_bytes, dcq_stream_t stream) {
+  return dcq_hessian_accumulate_ex(x, storage, T, C, alpha, H, workspace, workspace_bytes, 0, nullptr, nullptr, stream);
+}
+
+int dcq_hessian_accumulate_ex(const void* x, int32_t storage, int64_t T, int64_t C, float alpha, float* H,
+                              void* workspace, int64_t workspace_bytes, int32_t round_width, void* start_event,
+                              void* stop_event, dcq_stream_t stream) {
+  hipEvent_t prof_start = static_cast<hipEvent_t>(start_event), prof_stop = static_cast<hipEvent_t>(stop_event);
   DCQ_REQUIRE(T >= 0 && C > 0, DCQ_ERR_ARGUMENT, "bad sizes T=%lld C=%lld", (long long)T, (long long)C);
   if (T == 0) return DCQ_OK;
   DCQ_REQUIRE(x && H && workspace, DCQ_ERR_ARGUMENT, "NULL buffer");
@@ -958,7 +956,7 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
                        "hipFuncSetAttribute(syrk LDS)");
     if (rc != DCQ_OK) return rc;
   }
-  if (g_prof_start) (void)hipEventRecord(g_prof_start, s);
+  if (prof_start) (void)hipEventRecord(prof_start, s);
   // One launch per round of (tile, split) work items, as many as the chip has compute units (one workgroup each).
   // All workgroups of a launch start together and do the same amount of work, so the 32 of an XCD walk their
   // operand panels in step and each 128-byte line is fetched into that XCD's L2 once for all of them.  In one big
@@ -971,14 +969,13 @@ int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C,
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8)
       per_launch = cus / 8 * 8;  // whole groups of 8: workgroup i runs on XCD i mod 8
   }
-  if (g_round_width >= 8 && g_round_width < per_launch) per_launch = g_round_width / 8 * 8;
+  if (round_width >= 8 && round_width < per_launch) per_launch = round_width / 8 * 8;
   for (int first = 0; first < total; first += per_launch) {
     p.first_logical = first;
     const int n = total - first < per_launch ? total - first : per_launch;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(n)), dim3(kSyrkThreads), lds, s, p);
   }
-  if (g_prof_stop) (void)hipEventRecord(g_prof_stop, s);
-  g_prof_start = g_prof_stop = nullptr;
+  if (prof_stop) (void)hipEventRecord(prof_stop, s);
   DCQ_LAUNCH_CHECK("syrk_kernel launch");
   if (h.splits > 1) {
     hipLaunchKernelGGL(syrk_reduce_kernel, dim3(static_cast<unsigned>(h.num_tiles) * (kTile / kReduceRows)), dim3(256), 0, s,

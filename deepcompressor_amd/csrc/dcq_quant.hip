@@ -496,6 +496,31 @@ __global__ __launch_bounds__(kBlock) void codebook_kernel(const typename Storage
   }
 }
 
+// float64 tensors against a float64 table: the reference's kernel is instantiated for float and double
+// (AT_DISPATCH_FLOATING_TYPES, csrc/quantize/quantize.cu:145) and compares in the tensor's own type
+__global__ __launch_bounds__(kBlock) void codebook_f64_kernel(const double* x, double* y, int64_t n, const double* codebook,
+                                                              int C) {
+  __shared__ double cb[256];
+  for (int i = threadIdx.x; i < C; i += kBlock) cb[i] = codebook[i];
+  __syncthreads();
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const double v = x[i];
+    int lo = 0;
+    double lval = cb[0];
+#pragma unroll 1
+    for (int bit = 1 << (31 - __clz(C)); bit; bit >>= 1) {
+      const int next = lo | bit;
+      const double nval = cb[next < C ? next : C - 1];
+      const bool take = next < C && nval <= v;
+      lo = take ? next : lo;
+      lval = take ? nval : lval;
+    }
+    const double hval = cb[lo + (lo < C - 1)];
+    y[i] = (v + v < lval + hval) ? lval : hval;
+  }
+}
+
 template <int ST>
 __global__ __launch_bounds__(kBlock) void prescale_kernel(const typename Storage<ST>::elem_t* x, int64_t n, int64_t S,
                                                           const float* outer, float lo, float hi, float* out) {
@@ -613,8 +638,9 @@ extern "C" {
 const char* dcq_version(void) { return "dcq 0.1 (gfx950)"; }
 const char* dcq_last_error(void) { return g_error; }
 
-int dcq_round_to_codebook(const void* x, void* y, int64_t n, int32_t storage, const float* codebook,
+int dcq_round_to_codebook(const void* x, void* y, int64_t n, int32_t storage, const void* codebook_values,
                           int32_t codebook_size, dcq_stream_t stream) {
+  const float* codebook = static_cast<const float*>(codebook_values);
   DCQ_REQUIRE(n >= 0, DCQ_ERR_ARGUMENT, "n < 0");
   if (n == 0) return DCQ_OK;
   DCQ_REQUIRE(x && y && codebook, DCQ_ERR_ARGUMENT, "NULL buffer");
@@ -634,6 +660,10 @@ int dcq_round_to_codebook(const void* x, void* y, int64_t n, int32_t storage, co
     case DCQ_BF16:
       hipLaunchKernelGGL(codebook_kernel<DCQ_BF16>, dim3(grid), dim3(kBlock), 0, s, static_cast<const uint16_t*>(x),
                          static_cast<uint16_t*>(y), n, codebook, codebook_size);
+      break;
+    case DCQ_F64:
+      hipLaunchKernelGGL(codebook_f64_kernel, dim3(grid), dim3(kBlock), 0, s, static_cast<const double*>(x),
+                         static_cast<double*>(y), n, static_cast<const double*>(codebook_values), codebook_size);
       break;
     default:
       set_error("bad storage %d", storage);

@@ -30,12 +30,19 @@ class Codebook:
         """Nearest table value of every element; a tie goes to the larger value."""
         if not tensor.is_cuda:
             raise _lib.DcqError("Codebook.round runs on the GPU only (no CPU path)")
-        work_dtype = tensor.dtype if tensor.dtype in (torch.float32, torch.float16, torch.bfloat16) else torch.float32
+        # the reference compares in the table's dtype (data/codebook.py:48-50): a float64 table or tensor takes the
+        # float64 kernel, everything else float32 (16-bit tensors are widened inside the kernel)
+        double = torch.float64 in (tensor.dtype, self.values.dtype)
+        if double:
+            work_dtype = table_dtype = torch.float64
+        else:
+            work_dtype = tensor.dtype if tensor.dtype in (torch.float32, torch.float16, torch.bfloat16) else torch.float32
+            table_dtype = torch.float32
         x = tensor.to(work_dtype).contiguous()
-        table = self.values.to(device=x.device, dtype=torch.float32).contiguous()
+        table = self.values.to(device=x.device, dtype=table_dtype).contiguous()
         y = torch.empty_like(x)
         _lib.check(
-            _lib.lib().dcq_round_to_codebook(_lib.ptr(x), _lib.ptr(y), x.numel(), _lib.storage_of(x.dtype),
+            _lib.lib().dcq_round_to_codebook(_lib.ptr(x), _lib.ptr(y), x.numel(), 3 if double else _lib.storage_of(x.dtype),
                                              _lib.ptr(table), table.numel(), _lib.stream_of(x.device)),
             "dcq_round_to_codebook",
         )

@@ -192,9 +192,21 @@ class QuantScaleInfo:
                     vavg = x2d.to(torch.float32).mean(dim=1).contiguous()
             ratio = dr.ratio
             if isinstance(ratio, torch.Tensor):
-                if ratio.numel() != 1:
-                    raise NotImplementedError("per-group range ratios are not implemented")
-                ratio = float(ratio)
+                if ratio.numel() == 1:
+                    ratio = float(ratio)
+                else:
+                    # one ratio per group, per group of channels ... (what a range search on a non-static tensor
+                    # stores, calib/range.py:164): DynamicRange.measure's `vmax * self.ratio` with broadcasting
+                    # (data/range.py:331-344), on the per-group arrays
+                    assert not static, "a ratio tensor scales a measured range"
+                    per_group = ratio.to(device=tensor.device, dtype=torch.float32).expand(keep_view).reshape(-1)
+                    if vavg is not None:
+                        vmag = torch.maximum(vmax - vavg, vavg - vmin) * per_group
+                        vmax, vmin, vavg = vavg + vmag, vavg - vmag, None
+                    else:
+                        vmax = vmax * per_group
+                        vmin = vmin * per_group if vmin is not None else None
+                    ratio = None
             if has_exp:
                 exp_raw, _ = engine.range_to_scale(self._native_exponent(tensor.device), vmax, vmin, ratio=ratio,
                                                    static_max=fmt(dr.max),

@@ -98,41 +98,40 @@ def clear_hessian_cache() -> None:
         _prepared.clear()
 
 
-def prepare_hessians(caches, device: torch.device, world: int = 1, round_width: int = 0) -> list[torch.Tensor]:
+def prepare_hessians(caches, device: torch.device, world: int = 1, round_width: int = 0,
+                     profile_events: tuple | None = None) -> list[torch.Tensor]:
     """Compute the Hessian of every activation cache in ``caches`` now, one after the other on the current stream
     (each launch has the whole chip), and keep them for ``hessian_of`` calls from any thread until
-    ``clear_hessian_cache``.  The pipelines that consume them (inverse factor, sweeps) are latency-bound and may then
-    run concurrently on several streams without slowing the matrix-core SYRKs down.
+    ``clear_hessian_cache`` -- call that when the layer is done: every entry holds its cache's activation tensors
+    alive (multi-GB at the calibration sizes of a language model).  The pipelines that consume the Hessians (inverse
+    factor, sweeps) are latency-bound and may then run concurrently on several streams without slowing the
+    matrix-core SYRKs down.
 
     ``world`` > 1: the calibration tokens are sharded over the processes of the default group (every rank passes the
     cache of its own shard).  H is a sum over tokens, so each rank accumulates its shard with the weight 2 / (total
     number of samples) and the partial Hessians are all-reduced: every rank ends up with the same full H (the same
     as unsharded up to the order of the float32 sums).
 
-    ``round_width`` > 0: the SYRK takes at most that many compute units at a time (``dcq_hessian_round_width``), for
-    Hessians computed while latency-bound kernels of other streams need a free compute unit to start on."""
+    ``round_width`` > 0: the SYRK takes at most that many compute units at a time, for Hessians computed while
+    latency-bound kernels of other streams need a free compute unit to start on.  ``profile_events``: a pair of
+    ``torch.cuda.Event(enable_timing=True)`` recorded right before / after the SYRK launches of the first cache that
+    is not already prepared (a measurement hook)."""
     from ...parallel import all_reduce_sum
 
-    lib().dcq_hessian_round_width(int(round_width))
-    try:
-        return _prepare_hessians(caches, device, world, all_reduce_sum)
-    finally:
-        lib().dcq_hessian_round_width(0)
-
-
-def _prepare_hessians(caches, device, world, all_reduce_sum) -> list[torch.Tensor]:
     out = []
     for inputs in caches:
         key = _inputs_key(inputs, device)
         hit = _prepared_lookup(key, inputs)
         if hit is None:
+            events, profile_events = profile_events, None
             if world > 1:
                 # on the accelerator: the RCCL backend has no path for host tensors
                 total = all_reduce_sum(torch.tensor([float(inputs.num_samples)], dtype=torch.float64, device=device),
                                        world)
-                hit = all_reduce_sum(_compute_hessian(inputs, device, num_samples=int(total.item())), world)
+                hit = all_reduce_sum(_compute_hessian(inputs, device, num_samples=int(total.item()),
+                                                      round_width=round_width, profile_events=events), world)
             else:
-                hit = _compute_hessian(inputs, device)
+                hit = _compute_hessian(inputs, device, round_width=round_width, profile_events=events)
             with _prepared_lock:
                 _prepared[key] = (tuple(inputs.data), hit)
         out.append(hit)
@@ -192,14 +191,19 @@ def hessian_of(inputs: TensorCache, device: torch.device) -> torch.Tensor:
     return _hessian_cache["value"]
 
 
-def _compute_hessian(inputs: TensorCache, device: torch.device, num_samples: int | None = None) -> torch.Tensor:
+def _compute_hessian(inputs: TensorCache, device: torch.device, num_samples: int | None = None, round_width: int = 0,
+                     profile_events: tuple | None = None) -> torch.Tensor:
     hessian = None
     alpha = 2.0 / (inputs.num_samples if num_samples is None else num_samples)
-    for x in inputs.data:
+    last = len(inputs.data) - 1
+    for i, x in enumerate(inputs.data):
         x2 = inputs.reshape(x.view(-1, *x.shape[inputs.channels_dim:]))
         if hessian is None:
             hessian = torch.zeros((x2.shape[1], x2.shape[1]), device=device, dtype=torch.float32)
-        hessian_accumulate(hessian, x2.to(device=device, non_blocking=True), alpha)
+        start = profile_events[0] if profile_events is not None and i == 0 else None
+        stop = profile_events[1] if profile_events is not None and i == last else None
+        hessian_accumulate(hessian, x2.to(device=device, non_blocking=True), alpha, round_width=round_width,
+                           start_event=start, stop_event=stop)
     if hessian is not None and num_samples is None:
         _start_diag_mean(hessian)
     return hessian
@@ -248,9 +252,21 @@ def release_workspaces() -> None:
     _state.workspaces.clear()
 
 
-def hessian_accumulate(hessian: torch.Tensor, x: torch.Tensor, alpha: float) -> None:
+def _event_handle(event) -> C.c_void_p | None:
+    """hipEvent_t of a ``torch.cuda.Event`` (torch creates it lazily on the first record: record once if needed)."""
+    if event is None:
+        return None
+    if not event.cuda_event:
+        event.record()
+    return C.c_void_p(event.cuda_event)
+
+
+def hessian_accumulate(hessian: torch.Tensor, x: torch.Tensor, alpha: float, *, round_width: int = 0,
+                       start_event=None, stop_event=None) -> None:
     """hessian[C][C] += alpha * x^T x for x[N][C] on the same GPU: 16-bit activations take the bf16 / f16
-    matrix-core SYRK, float32 activations the float32 matrix-core GEMM (x^T is the transposed-A operand)."""
+    matrix-core SYRK, float32 activations the float32 matrix-core GEMM (x^T is the transposed-A operand).
+    ``round_width``, ``start_event`` / ``stop_event`` (``torch.cuda.Event`` with timing): the scheduling hint and the
+    measurement hook of ``dcq_hessian_accumulate_ex`` (16-bit activations only)."""
     assert x.ndim == 2 and hessian.shape == (x.shape[1], x.shape[1]) and hessian.dtype == torch.float32
     x = x.contiguous()
     if x.dtype == torch.float32:
@@ -261,8 +277,9 @@ def hessian_accumulate(hessian: torch.Tensor, x: torch.Tensor, alpha: float) -> 
     T, Cn = x.shape
     nbytes = lib().dcq_hessian_workspace_bytes(T, Cn)
     ws = _workspace(x.device, nbytes)
-    check(lib().dcq_hessian_accumulate(ptr(x), storage_of(x.dtype), T, Cn, float(alpha), ptr(hessian), ptr(ws),
-                                       ws.numel(), stream_of(x.device)), "dcq_hessian_accumulate")
+    check(lib().dcq_hessian_accumulate_ex(ptr(x), storage_of(x.dtype), T, Cn, float(alpha), ptr(hessian), ptr(ws),
+                                          ws.numel(), int(round_width), _event_handle(start_event),
+                                          _event_handle(stop_event), stream_of(x.device)), "dcq_hessian_accumulate_ex")
 
 
 def gemm_f32(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0,
@@ -368,12 +385,15 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     engine._require_gpu(tensor)
     view = tensor.view(view_shape)
     view_shape = view.shape
-    if len(view_shape) != 4:
-        raise NotImplementedError("GPTQ is implemented for 2-D weights (linear layers)")
-    n_rg, rg_size, n_cg, cg_size = view_shape
+    assert len(view_shape) >= 4 and len(view_shape) % 2 == 0, "view_shape is (#g0, gs0, #g1, gs1, ...)"
+    # (#g0, gs0, #g1, gs1, #g2, gs2, ...) -> rows (#g0 gs0) x columns (#g1 #g2 ... gs1 gs2 ...): the columns of one
+    # quantization group side by side (gptq.py:168-178); for a linear's (#g0, gs0, #g1, gs1) nothing moves
+    n_view = len(view_shape)
+    n_rg, rg_size = view_shape[0], view_shape[1]
+    n_cg, cg_size = view_shape[2::2].numel(), view_shape[3::2].numel()
     R, Cn = n_rg * rg_size, n_cg * cg_size
     dev = tensor.device
-    W = view.reshape(R, Cn)
+    W = view.permute(0, 1, *range(2, n_view, 2), *range(3, n_view, 2)).reshape(R, Cn) if n_view > 4 else view.reshape(R, Cn)
     assert W.dtype in (torch.float32, torch.float16, torch.bfloat16), "the weight must be float32 / float16 / bfloat16"
     # ---- Hessian (shared, never modified), dead channels, act-order permutation, damping, inverse factor
     hessian = hessian_of(inputs, dev) if hessian is None else hessian
@@ -383,7 +403,8 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     step = engine.make_step(quant_dtype=quant_dtype, zero_domain=zero_domain, tensor_quant_range=qr,
                             quant_range=quant_range, scale_dtype=torch.float32, zero_dtype=torch.float32,
                             range_bound=range_bound, q_span=1.0, device=dev)
-    s2 = scale.to(torch.float32).expand(n_rg, 1, n_cg, 1).reshape(n_rg, n_cg).contiguous()
+    keep = [v if i % 2 == 0 else 1 for i, v in enumerate(view_shape)]
+    s2 = scale.to(torch.float32).expand(keep).reshape(n_rg, n_cg).contiguous()
     zero_is_number = isinstance(zero, (int, float)) or zero.numel() == 1
     z2, z_scalar = None, 0.0
     if zero_domain is not None:
@@ -418,4 +439,9 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
         assert attempt < gptq_config.num_inv_tries, "Hessian could not be factorised"
     Q = engine.gather_columns(Q, inverse_perm)
     engine.assert_finite(Q, "GPTQ Quantized tensor")
-    return Q.reshape(n_rg, rg_size, n_cg, cg_size).contiguous()
+    if n_view == 4:
+        return Q.reshape(n_rg, rg_size, n_cg, cg_size).contiguous()
+    # back to (#g0, gs0, #g1, gs1, #g2, gs2, ...) (gptq.py:272-281)
+    half = n_view // 2
+    order = [0, 1] + [d for i in range(1, half) for d in (1 + i, half + i)]
+    return Q.reshape(view_shape[:2] + view_shape[2::2] + view_shape[3::2]).permute(order).reshape(view_shape).contiguous()

@@ -34,7 +34,7 @@ enum dcq_status {
 };
 
 /* storage type of a tensor in memory */
-enum dcq_storage { DCQ_F32 = 0, DCQ_F16 = 1, DCQ_BF16 = 2, DCQ_F64 = 3 /* dcq_gemm_f64 operands only */ };
+enum dcq_storage { DCQ_F32 = 0, DCQ_F16 = 1, DCQ_BF16 = 2, DCQ_F64 = 3 /* dcq_gemm_f64 operands and dcq_round_to_codebook only */ };
 
 /* deepcompressor/data/zero.py:9-13 */
 enum dcq_zero_domain { DCQ_ZERO_NONE = 0, DCQ_ZERO_PRE_SCALE = 1, DCQ_ZERO_POST_SCALE = 2 };
@@ -82,9 +82,13 @@ const char* dcq_last_error(void);
  * Codebook rounding.  Replaces _C.round_to_nearest_in_codebook_cuda(tensor, codebook, inplace, bnb)
  * (deepcompressor/csrc/pybind.cpp:6-10, csrc/quantize/quantize.cu:104-160) called from
  * Codebook.round (data/codebook.py:37-50).  y may alias x.  x, y: n values of `storage` type.
+ * `codebook`: the table's values, ascending, float32 -- or float64 when `storage` is DCQ_F64: the reference
+ * instantiates its kernel for float and double tensors (quantize.cu:145) with the table in the tensor's type, and
+ * compares in that type.  DCQ_F16 / DCQ_BF16 tensors (no counterpart in the reference, whose caller casts to the
+ * table's type first) are widened to float32 for the comparison.
  * The reference's `bnb` variant is never selected by its own callers and is not provided.
  * ------------------------------------------------------------------------------------------- */
-int dcq_round_to_codebook(const void* x, void* y, int64_t n, int32_t storage, const float* codebook,
+int dcq_round_to_codebook(const void* x, void* y, int64_t n, int32_t storage, const void* codebook,
                           int32_t codebook_size, dcq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -292,21 +296,21 @@ int dcq_selftest_division(const float* x, const float* s, float* fast, float* re
  * ------------------------------------------------------------------------------------------- */
 int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C);
 
-/* Measurement hook (no reference counterpart): the calling thread's next dcq_hessian_accumulate records
- * `start` right before and `stop` right after its matrix-core kernel launches (one per round of workgroups) on the
- * call's stream (hipEvent_t
- * handles, created by the caller with timing enabled), then forgets them.  Pass NULLs to disarm. */
-void dcq_profile_next_hessian(void* start, void* stop);
-
-/* Scheduling hint (no reference counterpart): dcq_hessian_accumulate calls of the calling thread launch their
- * matrix-core kernel in rounds of at most `workgroups` workgroups (rounded down to a multiple of 8, one per XCD in
- * turn) instead of one per compute unit, which leaves the other compute units to kernels of other streams: a
- * Hessian that runs beside latency-bound single-workgroup kernels otherwise holds every compute unit until a
- * workgroup of its round ends.  0 restores the default.  Results do not depend on it. */
-void dcq_hessian_round_width(int32_t workgroups);
-
 int dcq_hessian_accumulate(const void* x, int32_t storage, int64_t T, int64_t C, float alpha, float* H, void* workspace,
                            int64_t workspace_bytes, dcq_stream_t stream);
+
+/* dcq_hessian_accumulate with its two optional controls as arguments (neither has a reference counterpart, neither
+ * changes the result):
+ *   round_width  : scheduling hint -- launch the matrix-core kernel in rounds of at most this many workgroups (rounded
+ *                  down to a multiple of 8, one per XCD in turn) instead of one per compute unit, which leaves the
+ *                  other compute units to kernels of other streams: a Hessian that runs beside latency-bound
+ *                  single-workgroup kernels otherwise holds every compute unit until a workgroup of its round ends.
+ *                  0: one workgroup per compute unit.
+ *   start_event, stop_event : measurement -- hipEvent_t handles (created by the caller with timing enabled) recorded
+ *                  on `stream` right before and right after the matrix-core kernel launches (one per round); NULL: none. */
+int dcq_hessian_accumulate_ex(const void* x, int32_t storage, int64_t T, int64_t C, float alpha, float* H,
+                              void* workspace, int64_t workspace_bytes, int32_t round_width, void* start_event,
+                              void* stop_event, dcq_stream_t stream);
 
 int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64_t C, const float* U, int32_t c0,
                          int32_t bc, const float* scale, const float* zero, float zero_scalar, int32_t row_group_size,

@@ -275,6 +275,39 @@ def gen_gptq(ref) -> None:
     np.savez_compressed(os.path.join(OUT, "gptq.npz"), **arrays)
     with open(os.path.join(OUT, "gptq.json"), "w") as f:
         json.dump(meta, f, indent=1)
+    gen_gptq_conv(ref)
+
+
+def gen_gptq_conv(ref) -> None:
+    """GPTQ on a convolution weight, whose view has more than two pairs of dimensions: the reference moves the
+    columns of a quantization group side by side (quantizer/kernel/gptq.py:168-178) and back (:272-281).  Two group
+    geometries: whole receptive fields of 4 channels (nothing moves) and one kernel row of all channels per group (the
+    columns are re-ordered, while the Hessian stays in the activations' unfolded order, as the reference has it)."""
+    from deepcompressor.data.cache import TensorCache
+    from deepcompressor.data.utils.reshape import ConvInputReshapeFn
+    from deepcompressor.quantizer.kernel.gptq import QuantGptqConfig
+
+    arrays, meta = {}, {}
+    O, Cin, K = 24, 8, 3
+    for tag, groups in (("fields", ((1, 4, -1),)), ("kernel_rows", ((1, -1, 1, -1),))):
+        case = dict(dtype="uint4", zero="PostScale", groups=groups, sdt=("f16",), shape=(O, Cin, K, K))
+        g = torch.Generator().manual_seed(len(tag))
+        w = (torch.randn(O, Cin, K, K, generator=g) * 0.05).to(torch.bfloat16)
+        gains = torch.exp(torch.randn(1, Cin, 1, 1, generator=g) * 0.7)
+        x = (torch.randn(4, Cin, 10, 10, generator=g) * gains).to(torch.bfloat16)
+        reshape = ConvInputReshapeFn((K, K), (1, 1), (1, 1), (1, 1))
+        q = _build_quantizer(ref, case)
+        cache = TensorCache([x], channels_dim=1, reshape=reshape, num_cached=1, num_total=1, num_samples=4)
+        kern = QuantGptqConfig(damp_percentage=0.01, block_size=128, num_inv_tries=250, hessian_block_size=512)
+        qt = q.quantize(w, kernel=kern, inputs=cache, return_with_dequant=False, return_with_quant=True)
+        dq = q.quantize(w, kernel=kern, inputs=cache, return_with_dequant=True, return_with_quant=False)
+        arrays[f"{tag}|w"], arrays[f"{tag}|x"] = _np(w), _np(x)
+        arrays[f"{tag}|codes"], arrays[f"{tag}|dequant"] = _np(qt.qdata), _np(dq.data)
+        arrays[f"{tag}|scale"], arrays[f"{tag}|zero"] = _np(qt.scale.data), _np(qt.zero)
+        meta[tag] = dict(case=case, view_shape=list(qt.view_shape), num_samples=4)
+    np.savez_compressed(os.path.join(OUT, "gptq_conv.npz"), **arrays)
+    with open(os.path.join(OUT, "gptq_conv.json"), "w") as f:
+        json.dump(meta, f, indent=1)
 
 
 def gen_rotate(ref) -> None:

@@ -416,3 +416,34 @@ def test_three_progressive_steps_match_reference(tag):
     both = q.quantize(x, return_with_dequant=True, return_with_quant=True, **kwargs)
     assert torch.equal(both.data, deq.data) and both.qdata.dtype == torch.float32
     assert torch.equal(both.qdata.to(x.dtype), deq.data)  # the reference's aliasing: qdata is the float32 dequantization
+
+
+@pytest.mark.parametrize("cname", ["sint4_g128_f16s", "uint4_post_g128_f16s", "uint4_pre_g128_f16s", "sfp4_g32_f16s"])
+@pytest.mark.parametrize("shape", ["group", "channel_group", "row"])
+def test_ratio_tensors_scale_each_groups_range(cname, shape):
+    """``DynamicRange(ratio=tensor)`` -- what a range search on a non-static tensor stores (calib/range.py:164): every
+    group's measured range times its own ratio (data/range.py:331-344, broadcasting).  Checked group by group against
+    the same quantizer run with that group's ratio as a number."""
+    from deepcompressor_amd.data.range import DynamicRange
+    case = FQ.meta["cases"][cname]
+    q = build_quantizer(case)
+    g = torch.Generator().manual_seed(12)
+    rows, cols = 24, 512
+    gs = case["groups"][-1][-1]
+    w = (torch.randn(rows, cols, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    choices = [1.0, 0.9, 0.625]
+    full = (rows, 1, cols // gs, 1)
+    ratio_shape = {"group": full, "channel_group": (1, 1, cols // gs, 1), "row": (rows, 1, 1, 1)}[shape]
+    pick = torch.randint(0, len(choices), ratio_shape, generator=g)
+    ratio = torch.tensor(choices)[pick].cuda()
+    got = q.quantize(w, dynamic_range=DynamicRange(ratio=ratio), return_with_quant=False).data.view(rows, cols // gs, gs)
+    codes = q.quantize(w, dynamic_range=DynamicRange(ratio=ratio), return_with_dequant=False, return_with_quant=True)
+    which = pick.expand(full).reshape(rows, cols // gs).cuda()
+    for i, r in enumerate(choices):
+        one = q.quantize(w, dynamic_range=DynamicRange(ratio=r), return_with_dequant=False, return_with_quant=True)
+        want = q.quantize(w, dynamic_range=DynamicRange(ratio=r)).data.view(rows, cols // gs, gs)
+        mask = which == i
+        assert mask.any()
+        assert torch.equal(got[mask], want[mask]), (cname, shape, r)
+        assert torch.equal(codes.qdata.view(rows, cols // gs, gs)[mask], one.qdata.view(rows, cols // gs, gs)[mask])
+        assert torch.equal(codes.scale.data.view(rows, cols // gs)[mask], one.scale.data.view(rows, cols // gs)[mask])

@@ -47,20 +47,19 @@ def test_hessian_matches_float64(T, C, dt):
 @pytest.mark.parametrize("T,C", [(16384, 4096), (8192, 2560), (4000, 1000)])
 @pytest.mark.parametrize("width", [8, 100, 224])
 def test_hessian_does_not_depend_on_the_round_width(T, C, width):
-    """dcq_hessian_round_width only changes how many workgroups are launched at a time (direct and transposed-copy
-    kernels, several K splits): the Hessian is the same bit for bit."""
-    from deepcompressor_amd._lib import lib
+    """The round width of dcq_hessian_accumulate_ex only changes how many workgroups are launched at a time (direct and
+    transposed-copy kernels, several K splits): the Hessian is the same bit for bit; the events it is handed bracket
+    the launches."""
     g = torch.Generator().manual_seed(T + C)
     x = (torch.randn(T, C, generator=g) * torch.exp(torch.randn(C, generator=g))).to(torch.bfloat16).cuda()
     base = torch.zeros(C, C, device="cuda")
     hessian_accumulate(base, x, 2.0 / T)
-    lib().dcq_hessian_round_width(width)
-    try:
-        narrow = torch.zeros(C, C, device="cuda")
-        hessian_accumulate(narrow, x, 2.0 / T)
-    finally:
-        lib().dcq_hessian_round_width(0)
+    narrow = torch.zeros(C, C, device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    hessian_accumulate(narrow, x, 2.0 / T, round_width=width, start_event=e0, stop_event=e1)
+    torch.cuda.synchronize()
     assert torch.equal(base, narrow)
+    assert e0.elapsed_time(e1) > 0.0
 
 
 def test_hessian_float32_activations():
@@ -406,3 +405,33 @@ def test_gather_and_finite_check_on_empty_inputs():
     out = engine.gather_columns(empty, torch.randperm(256).cuda())
     assert out.shape == (0, 256) and out.dtype == torch.float32
     engine.assert_finite(torch.empty(0, device="cuda"), "Quantized tensor")
+
+
+GC = load_golden("gptq_conv")
+
+
+@pytest.mark.parametrize("tag", sorted(GC.meta))
+def test_gptq_on_a_convolution_weight_matches_reference_fixture(tag):
+    """Views with more than two pairs of dimensions (a convolution's (out, in, kh, kw) weight): the columns of a
+    quantization group are moved side by side for the sweep and back afterwards as the reference does
+    (quantizer/kernel/gptq.py:168-178, 272-281), the Hessian comes from the unfolded inputs."""
+    from deepcompressor_amd.data.utils.reshape import ConvInputReshapeFn
+    m = GC.meta[tag]
+    w_np, x_np = GC[f"{tag}|w"], GC[f"{tag}|x"]
+    w, x = to_device(w_np, "bf16"), to_device(x_np, "bf16")
+    q = build_quantizer(m["case"])
+    cache = TensorCache([x], channels_dim=1, reshape=ConvInputReshapeFn((3, 3), (1, 1), (1, 1), (1, 1)), num_cached=1,
+                        num_total=1, num_samples=m["num_samples"])
+    kern = QuantGptqConfig(damp_percentage=0.01, block_size=128, num_inv_tries=250, hessian_block_size=512)
+    qt = q.quantize(w, kernel=kern, inputs=cache, return_with_dequant=False, return_with_quant=True)
+    dq = q.quantize(w, kernel=kern, inputs=cache)
+    assert list(qt.view_shape) == m["view_shape"]
+    np.testing.assert_array_equal(to_np(qt.scale.data), GC[f"{tag}|scale"])
+    np.testing.assert_array_equal(to_np(qt.zero), GC[f"{tag}|zero"])
+    codes, want = to_np(qt.qdata), GC[f"{tag}|codes"]
+    assert codes.shape == want.shape
+    same = (codes == want).mean()
+    assert same > 0.99, f"only {same:.4f} of the codes equal the reference's"
+    y = lambda wt: torch.nn.functional.conv2d(torch.from_numpy(x_np).double(), torch.from_numpy(wt).double(), padding=1)  # noqa: E731
+    err = ((y(to_np(dq.data)) - y(GC[f"{tag}|dequant"])).abs().max() / y(GC[f"{tag}|dequant"]).abs().max()).item()
+    assert err < 1e-3, err

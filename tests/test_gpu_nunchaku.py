@@ -83,3 +83,26 @@ def test_w8_conversion_matches_reference(dt):
     w, s, b = convert_to_nunchaku_w8x8y16_linear_weight(t("weight"), t("scale"), t("bias"))
     for name, got in (("weight", w), ("scale", s), ("bias", b)):
         np.testing.assert_array_equal(host(got), NK[f"w8|{dt}|out|{name}"], err_msg=name)
+
+
+@pytest.mark.parametrize("tag", LINEARS[:2])
+def test_pointwise_convolution_weight_converts_like_its_matrix(tag):
+    """A [out][in][1][1] weight is flattened first, and its scale is checked against the flattened weight's rank as
+    the reference does (backend/nunchaku/convert.py:24-30, 37); the quantizer's own scale of such a weight (one more
+    (1, 1) pair per kernel dimension) is taken as well.  Same packed tensors as the linear either way."""
+    m = NK.meta[tag]
+    kw = linear_inputs(tag)
+    to = lambda a: torch.from_numpy(a).to(DT[m["dtype"]]).cuda()  # noqa: E731
+    for k, v in list(kw.items()):
+        if isinstance(v, np.ndarray):
+            kw[k] = to(v)
+        elif isinstance(v, tuple):
+            kw[k] = tuple(to(a) for a in v)
+    want = convert_to_nunchaku_w4x4y16_linear_state_dict(**kw)
+    conv = dict(kw, weight=kw["weight"][:, :, None, None])
+    got = convert_to_nunchaku_w4x4y16_linear_state_dict(**conv)  # 4-D scale, as the reference accepts
+    assert sorted(got) == sorted(want) and all(torch.equal(got[k], want[k]) for k in want)
+    if kw["scale"].numel() > 1:
+        conv["scale"] = kw["scale"].reshape(*kw["scale"].shape, 1, 1, 1, 1)  # 8-D: the quantizer's view of the 4-D weight
+        got = convert_to_nunchaku_w4x4y16_linear_state_dict(**conv)
+        assert all(torch.equal(got[k], want[k]) for k in want)

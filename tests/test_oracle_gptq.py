@@ -51,3 +51,42 @@ def dequant(q, base, step, shape):
     if step.zero_domain == "PostScale":
         d = d - base["zero"]
     return d.reshape(shape).astype(np.float32)
+
+
+GC = load_golden("gptq_conv")
+
+
+def conv_columns(w, view):
+    """(#g0, gs0, #g1, gs1, #g2, gs2, ...) -> rows x columns with each group's columns side by side
+    (deepcompressor/quantizer/kernel/gptq.py:168-178), and the function that undoes it (:272-281)."""
+    n = len(view)
+    order = [0, 1] + list(range(2, n, 2)) + list(range(3, n, 2))
+    mat = w.reshape(view).transpose(order).reshape(view[0] * view[1], -1)
+    inverse = np.argsort(order)
+    moved = [view[i] for i in order]
+    return mat, (lambda q: q.reshape(moved).transpose(inverse).reshape(view))
+
+
+def unfold3x3(x):
+    """[batch][C][H][W] -> [batch * H * W][C * 9], padding 1: the rows a 3 x 3 convolution's weight matrix multiplies."""
+    b, c, h, w = x.shape
+    padded = np.pad(x, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    cols = np.stack([padded[:, :, i:i + h, j:j + w] for i in range(3) for j in range(3)], axis=2)  # b, c, 9, h, w
+    return cols.reshape(b, c * 9, h * w).transpose(0, 2, 1).reshape(-1, c * 9)
+
+
+@pytest.mark.parametrize("tag", sorted(GC.meta))
+def test_gptq_oracle_on_a_convolution_weight(tag):
+    m = GC.meta[tag]
+    spec = qo.spec_from_case(m["case"])
+    w, x = GC[f"{tag}|w"], GC[f"{tag}|x"]
+    view = m["view_shape"]
+    base = qo.fake_quantize(w, "bf16", spec)
+    np.testing.assert_array_equal(base["scale"].reshape(-1), GC[f"{tag}|scale"].reshape(-1))
+    mat, restore = conv_columns(w, view)
+    n_cg, cg = int(np.prod(view[2::2])), int(np.prod(view[3::2]))
+    codes = go.gptq_codes(mat, unfold3x3(x), m["num_samples"], spec.steps[0], base["scale"].reshape(view[0], n_cg),
+                          base["zero"].reshape(view[0], n_cg), (view[0], view[1], n_cg, cg))
+    codes = restore(codes).reshape(w.shape)
+    want = GC[f"{tag}|codes"].reshape(w.shape)
+    assert (codes == want).mean() > 0.99, float((codes == want).mean())
