@@ -14,6 +14,7 @@
 // rows R[k][:] are at once the A operand (transposed) and the B operand of the trailing update.
 #include "dcq_common.cuh"
 
+#include <atomic>
 #include <mutex>
 
 namespace dcq {
@@ -204,7 +205,7 @@ template <bool A_KMAJOR, int T>
 static int launch_gemm_variant(const GemmParams& p, hipStream_t s) {
   constexpr size_t lds = 2 * 2 * GemmStep<T>::value * (T + 4) * sizeof(float);
   auto kern = gemm_f32_kernel<A_KMAJOR, T>;
-  static bool configured[64] = {};
+  static std::atomic<bool> configured[64];  // (set twice by racing first calls at worst: the attribute call is idempotent)
   int dev = 0;
   int rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
   if (rc != DCQ_OK) return rc;
@@ -826,7 +827,7 @@ static int factor_invert(float* A, float* X, float* T, int64_t np, int lo, int h
     return DCQ_OK;
   }
   if (hi - lo == 2) {
-    static bool configured[64] = {};
+    static std::atomic<bool> configured[64];  // (set twice by racing first calls at worst: the attribute call is idempotent)
     int dev = 0;
     int rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
     if (rc != DCQ_OK) return rc;

@@ -244,12 +244,11 @@ class QuantizerImpl:
             bounds = step_info.tensor_quant_range
             develop = develop.view(step_info.tensor_view_shape).div(step_scale.data).view(shape)
             develop = develop.clamp_(min=bounds.min, max=bounds.max)
-        self.info = QuantInfo(steps=info.steps[-2:], needs_dequant_saturation=info.needs_dequant_saturation)
-        try:
-            inner = self._quantize_general(develop, kernel, tuple(scale[-2:]), zero, tuple(dynamic_range[-2:]),
-                                           round_delta, want_dequant, want_quant, kwargs)
-        finally:
-            self.info = info
+        # (the shortened plan is handed down, not swapped into ``self.info``: host threads that share this quantizer,
+        # one per HIP stream, must never see it)
+        last_two = QuantInfo(steps=info.steps[-2:], needs_dequant_saturation=info.needs_dequant_saturation)
+        inner = self._quantize_general(develop, kernel, tuple(scale[-2:]), zero, tuple(dynamic_range[-2:]),
+                                       round_delta, want_dequant, want_quant, kwargs, info=last_two)
         dequantized = None
         if want_dequant:
             d = inner.data
@@ -272,8 +271,9 @@ class QuantizerImpl:
 
     # ---- general path ------------------------------------------------------------------------
     def _quantize_general(self, tensor, kernel, scale, zero, dynamic_range, round_delta, want_dequant, want_quant,
-                          kwargs) -> QuantTensor:
-        info, shape, dtype, device = self.info, tensor.shape, tensor.dtype, tensor.device
+                          kwargs, info: QuantInfo | None = None) -> QuantTensor:
+        info = self.info if info is None else info
+        shape, dtype, device = tensor.shape, tensor.dtype, tensor.device
         n_steps = info.num_steps
         quant_scale = QuantScale()
         outer = outer_range = None  # previous step: per-group divisor (in the current step's group order) and clamp
@@ -281,7 +281,7 @@ class QuantizerImpl:
         native_rtn = kernel is None or type(kernel) is QuantRtnKernel
         if n_steps == 2 and native_rtn and round_delta is None and zero is None and scale[0] is None \
                 and scale[1] is None:
-            fused = self._quantize_two_steps_fused(tensor, dynamic_range, want_dequant, want_quant)
+            fused = self._quantize_two_steps_fused(tensor, dynamic_range, want_dequant, want_quant, info)
             if fused is not None:
                 return fused
         for i, step_info in enumerate(info.steps):
@@ -292,7 +292,7 @@ class QuantizerImpl:
             if i == n_steps - 1 and outer is not None and native_rtn and round_delta is None and scale[i] is None \
                     and zero is None:
                 fused = self._quantize_last_step_fused(tensor, step_info, dynamic_range[i], outer, outer_range,
-                                                       quant_scale, want_dequant, want_quant)
+                                                       quant_scale, want_dequant, want_quant, info)
                 if fused is not None:
                     return fused
             step_scale, step_zero = sinfo.quantize(scale=scale[i], zero=None if i < n_steps - 1 else zero,
@@ -408,11 +408,10 @@ class QuantizerImpl:
                                        errors_degree=errors_degree)
         return out.view(shape) if errors_degree is None else out
 
-    def _quantize_two_steps_fused(self, tensor, dynamic_range, want_dequant, want_quant) -> QuantTensor | None:
+    def _quantize_two_steps_fused(self, tensor, dynamic_range, want_dequant, want_quant, info) -> QuantTensor | None:
         """A two-step progressive quantizer whose first step has one group per row (QoQ W4: per-channel scales, then
         groups inside the row) in ONE pass over the tensor (``dcq_fake_quant_progressive``).  None when the
         configuration or the tensor is outside that kernel; the caller then goes step by step."""
-        info = self.info
         first, last = info.steps
         v0, v1 = first.tensor_view_shape, last.tensor_view_shape
         if tensor.ndim != 2 or not tensor.is_contiguous() or len(v0) != 4 or len(v1) != 4:
@@ -460,12 +459,12 @@ class QuantizerImpl:
                            view_shape=v1 if want_quant else None)
 
     def _quantize_last_step_fused(self, tensor, last, dyn, outer, outer_range, quant_scale, want_dequant,
-                                  want_quant) -> QuantTensor | None:
+                                  want_quant, info) -> QuantTensor | None:
         """The last step of a progressive quantizer in one pass over the tensor (``dcq_fake_quant_groups_outer``):
         range of clamp(x / outer), scale and zero of any one-level dtype, codes, dequantization back through the
         previous steps' scale.  None when the step needs the general path (several scale levels, a floating-point
         type with a zero point, a ratio on top of a fixed range)."""
-        sinfo, view, info = last.scale, last.tensor_view_shape, self.info
+        sinfo, view = last.scale, last.tensor_view_shape
         if not sinfo.is_single_level() or (sinfo.has_zero_point and last.quant_dtype.is_float_point):
             return None
         device, dtype = tensor.device, tensor.dtype

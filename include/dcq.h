@@ -370,7 +370,9 @@ int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, f
  * counterpart in the reference.  The workspace is a 36 MiB array built into the library (one copy per GPU, held until
  * the process ends), so n is limited to 2048 (DCQ_ERR_UNSUPPORTED beyond); nothing is allocated or freed.  Same
  * kernels and results as dcq_cholesky_inverse_upper, bit for bit.  All calls on one GPU share that array: calls that
- * overlap on one GPU (different streams or threads) race and must be serialised by the caller. */
+ * overlap on one GPU (different streams or threads) race and must be serialised by the caller.  The first call on a
+ * device does one-time host-side set-up (the array's address, kernel attributes): make one eager call per device
+ * before capturing calls into a HIP graph. */
 int dcq_cholesky_inverse_upper_static(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U,
                                       int32_t* info, dcq_stream_t stream);
 

