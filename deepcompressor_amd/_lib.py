@@ -90,6 +90,9 @@ _SIGNATURES = {
                                         _p, _p, _p, _p, _p, _p],
     "dcq_smooth_fake_quant_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _i64, _p, _i32, _i32, _i32, _f, _p, _p, _d,
                                      _p, _p, _p],
+    "dcq_smooth_quantize_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _i64, _p, _i32, _i32, _i32, _f, _p, _p, _p, _p],
+    "dcq_linear_candidate_errors": [_p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p, _i32,
+                                    _p],
     "dcq_channel_metric": [_p, _i32, _i64, _i64, _i64, _i32, _p, _p, _p],
     "dcq_scale_channels": [_p, _i32, _i64, _i64, _i64, _p, _i64, _i32, _p, _i32, _p],
     "dcq_range_search_groups": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _i32, _d, _p, _p, _p, _p, _p, _p, _i32,
@@ -117,6 +120,8 @@ def lib():
         handle.dcq_hessian_workspace_bytes.restype = C.c_int64
         handle.dcq_cholesky_workspace_bytes.argtypes = [_i64]
         handle.dcq_cholesky_workspace_bytes.restype = C.c_int64
+        handle.dcq_linear_candidate_errors_workspace.argtypes = [_i64, _i64, _i32]
+        handle.dcq_linear_candidate_errors_workspace.restype = C.c_int64
         handle.dcq_version.restype = C.c_char_p
         handle.dcq_last_error.restype = C.c_char_p
         _lib = handle

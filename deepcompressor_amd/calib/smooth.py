@@ -233,6 +233,7 @@ class SmoothCalibrator:
             assert all(y.shape[1] == num_out_channels for y in y_tensors)
             y_spans = spans_of(y_tensors, self.x_group_shape, self.config.a_spans, heads="expand", rope=rope)
             self.span_pairs = [(y_spans[a], x_spans[b]) for a, b in self.config.spans]
+        self._scales: torch.Tensor | None = None  # the candidates of these spans (_candidate_table)
         self.best_error: list[torch.Tensor] | None = None
         self.best_scale: torch.Tensor | None = None
         self.error_history: list[list[torch.Tensor]] = []  # every candidate's errors, in candidate order
@@ -240,13 +241,34 @@ class SmoothCalibrator:
     def get_best(self) -> torch.Tensor:
         return self.best_scale
 
+    def _candidate_table(self) -> torch.Tensor:
+        """Every candidate scale of the grid, [candidates][channels] in the develop dtype: row i is
+        ``get_smooth_scale`` of the i-th (alpha, beta) pair inside each pair of spans, all rows from a handful of
+        batched operations instead of one chain of small launches per candidate (float64 powers rounded to the span
+        dtype, as ``get_smooth_scale`` evaluates them)."""
+        if self._scales is not None:
+            return self._scales
+        device = self.span_pairs[0][0].device
+        alphas = torch.tensor([a for a, _ in self.alpha_beta_pairs], dtype=torch.float64, device=device).view(-1, 1)
+        betas = torch.tensor([b for _, b in self.alpha_beta_pairs], dtype=torch.float64, device=device).view(-1, 1)
+        assert all(0 <= a <= 1 and 0 <= b <= 1 for a, b in self.alpha_beta_pairs), \
+            "The smooth factors should be in [0, 1]."
+        tables = []
+        for a_span, b_span in self.span_pairs:
+            dtype = a_span.dtype
+            a64, b64 = a_span.to(torch.float64).view(1, -1), b_span.to(torch.float64).view(1, -1)
+            pa, pb, nb = a64.pow(alphas).to(dtype), b64.pow(betas).to(dtype), b64.pow(-betas).to(dtype)
+            scale = torch.where(alphas > 0, torch.where(betas > 0, pa / pb, pa), nb)
+            scale = scale.masked_fill_(scale == 0, 1)
+            finite = torch.isfinite(scale).all(dim=1, keepdim=True)
+            scale = torch.where(finite & ((alphas != 0) | (betas != 0)), scale, torch.ones_like(scale))
+            tables.append(scale.to(self.develop_dtype))
+        self._scales = torch.cat(tables)
+        return self._scales
+
     def _candidate_scale(self, candidate_id: int) -> torch.Tensor:
         """The candidate_id-th scale of the grid: (alpha, beta) pairs inside each pair of spans."""
-        alpha, beta = self.alpha_beta_pairs[candidate_id % len(self.alpha_beta_pairs)]
-        a_span, b_span = self.span_pairs[candidate_id // len(self.alpha_beta_pairs)]
-        if alpha == 0 and beta == 0:
-            return torch.ones_like(a_span, dtype=self.develop_dtype)
-        return get_smooth_scale(alpha_base=a_span, beta_base=b_span, alpha=alpha, beta=beta)
+        return self._candidate_table()[candidate_id]
 
     def ask(self) -> torch.Tensor:
         self.candidate = self._candidate_scale(self.candidate_id)
@@ -475,8 +497,14 @@ class SmoothCalibrator:
         orig_opts = [forward(ref_inputs, i) for i in range(num_batches)]
         for p, w in saved:
             p.data = w
+        # the evaluated module is the smoothed linear itself: every candidate from codes on the int8 matrix cores
+        table = None if outputs_centric else self._all_candidates_linear_outputs_error(
+            x_wgts, x_mods, eval_module, eval_inputs, eval_kwargs, orig_opts)
         while not self.is_done():
             self.ask()
+            if table is not None:
+                self.tell([table[self.candidate_id].view(1)])
+                continue
             if outputs_centric:
                 self._process_opts_centric_mod(x_wgts=x_wgts, y_wgts=y_wgts, x_mods=x_mods, y_mods=y_mods)
             else:
@@ -492,6 +520,71 @@ class SmoothCalibrator:
             self.tell([total])
         return self.get_best()
 
+
+    # bytes of int8 codes one call of the fused output scorer may hold (the candidates are taken in runs that fit)
+    LINEAR_SCORER_CODE_BYTES = 2 << 30
+
+    def _all_candidates_linear_outputs_error(self, x_wgts: list[nn.Parameter], x_mods: list[nn.Module] | None,
+                                             eval_module: nn.Module, eval_inputs: TensorsCache, eval_kwargs: dict,
+                                             orig_opts: list[torch.Tensor]) -> torch.Tensor | None:
+        """OutputsError of every candidate, float32 [candidates], when the evaluated module is the one smoothed
+        linear (smooth.py:575-625 puts Q(w s) / s into the module and Q(x / s) s in front of it, search.py:1011-1042
+        sums (y - y0)^2): s cancels in x' w'^T, so a candidate is one pass that writes int8 codes of w and of each
+        batch and an integer GEMM whose epilogue takes the difference from the outputs to match -- neither the
+        processed tensors nor the outputs are written.  None when the case is outside that path (another module
+        around the linear, a low-rank branch, hooks on the module, 16-bit tensors whose processed values the
+        reference rounds to 16 bits, degree other than 2, quantizers outside the fused candidate kernel): the
+        caller then evaluates the module candidate by candidate."""
+        if (self.num_iters != 1 or self.develop_dtype != torch.float32 or float(self.config.degree) != 2.0
+                or not (self.needs_w_quant_for_wgts and self.needs_x_quant_for_wgts)):
+            return None
+        if self.config.allow_low_rank and self.w_quantizer.is_enabled_low_rank():
+            return None
+        if (not isinstance(eval_module, nn.Linear) or x_mods is None or len(x_mods) != 1 or x_mods[0] is not eval_module
+                or len(x_wgts) != 1 or x_wgts[0] is not eval_module.weight or eval_kwargs
+                or eval_module._forward_pre_hooks or eval_module._forward_hooks):
+            return None
+        w = x_wgts[0].data
+        if w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous() or eval_inputs.num_tensors != 1:
+            return None
+        if self.x_quantizer.get_input_packager() is not None or self.x_quantizer.channels_dim not in (-1, None):
+            return None
+        bias = eval_module.bias
+        if bias is not None and bias.dtype != torch.float32:
+            return None
+        batches = eval_inputs.front().data
+        R, Cn = w.shape
+        if (Cn % 16 or len(batches) != len(orig_opts)
+                or any(x.dtype != torch.float32 or x.shape[-1] != Cn for x in batches)
+                or any(y.dtype != torch.float32 or y.shape[-1] != R for y in orig_opts)):
+            return None
+        scales = self._candidate_table().to(torch.float32)
+        K = scales.shape[0]
+        rows = max(x.numel() // Cn for x in batches)
+        run = max(1, min(K, self.LINEAR_SCORER_CODE_BYTES // ((R + rows) * Cn)))
+        totals = []
+        for begin in range(0, K, run):
+            cs = scales[begin:begin + run]
+            w_codes = self.w_quantizer.smooth_candidates(w, cs, divide_first=False, channels_dim=None,
+                                                         default_dtype=w.dtype, as_codes=True)
+            if w_codes is None:
+                return None
+            total = None
+            for x, y0 in zip(batches, orig_opts, strict=True):
+                x = x.to(w.device).contiguous()
+                x_codes = self.x_quantizer.smooth_candidates(x, cs, divide_first=True, channels_dim=-1,
+                                                             default_dtype=x.dtype, as_codes=True)
+                if x_codes is None:
+                    return None
+                gx, gw = Cn // x_codes[1].shape[-1], Cn // w_codes[1].shape[-1]
+                if min(gx, gw) < Cn and (max(gx, gw) % min(gx, gw) or min(gx, gw) % 128):
+                    return None
+                total = engine.linear_candidate_errors(x_codes[0], x_codes[1], w_codes[0], w_codes[1], bias,
+                                                       y0.to(w.device).reshape(-1, R), out=total)
+                del x_codes
+            totals.append(total)
+        errors = torch.cat(totals).to(torch.float32)
+        return errors if self.reduce_sum is None else self.reduce_sum(errors)
 
     def _calibrate_tensor(self, x_wgts: list[nn.Parameter], x_acts: TensorsCache | None,
                           orig_x_wgts: list[tuple[nn.Parameter, torch.Tensor]] | None) -> torch.Tensor:
@@ -540,7 +633,7 @@ class SmoothCalibrator:
         if channels_dim != 1 or any(w.ndim != 2 for w in wgts):
             return None
         # (the candidate list does not depend on the errors)
-        scales = torch.stack([self._candidate_scale(cid).to(torch.float32) for cid in range(self.population_size)])
+        scales = self._candidate_table().to(torch.float32)
         tables = []
         for w in wgts:
             errors = self.w_quantizer.smooth_candidates(w, scales, divide_first=False, channels_dim=None,

@@ -1428,6 +1428,8 @@ struct SmoothParams {
   float* errors;            // [K][G] float32 sums (unrounded), or NULL
   const uint16_t* table;    // 16-bit storage: |d|^degree by bit pattern, or NULL when the degree is 2
   float degree;
+  int8_t* codes;            // [K][G * S] codes minus zero point (the integer the scale multiplies), or NULL
+  float* code_scales;       // [K][G] with codes
 };
 
 template <int ST>
@@ -1522,7 +1524,7 @@ __global__ __launch_bounds__(256) void smooth_int_kernel(const SmoothParams sp) 
       float acc = 0.0f;
       for (int c = 0; c < chunks; ++c) {
         const int64_t off = static_cast<int64_t>(c) * TL + tl;
-        float v[VEC], m[VEC], o[VEC];
+        float v[VEC], m[VEC], o[VEC], kept[VEC];
         E::unpack(SINGLE ? keep : xg[off], v);
 #pragma unroll
         for (int i = 0; i < VEC; i += 4) {
@@ -1539,8 +1541,23 @@ __global__ __launch_bounds__(256) void smooth_int_kernel(const SmoothParams sp) 
           const float q = clamp_f(rintf(t), p.q_lo, p.q_hi);
           const float d = from_code<ZD>(q, sc, ze);
           o[i] = sp.divide_first ? d * m[i] : d / m[i];
+          kept[i] = ZD == DCQ_ZERO_PRE_SCALE ? q - ze : q;
         }
-        if (sp.errors) {
+        if (sp.codes) {
+          if (live) {
+            // the integer that the group's scale multiplies: code (minus a zero point in the code's own domain)
+            uint32_t word[VEC / 4];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              const uint32_t byte = static_cast<uint32_t>(static_cast<int>(kept[i])) & 0xffu;
+              word[i / 4] = (i % 4 == 0) ? byte : word[i / 4] | (byte << (8 * (i % 4)));
+            }
+            uint32_t* dst = reinterpret_cast<uint32_t*>(sp.codes + (static_cast<int64_t>(k) * p.G + g) * p.S) +
+                            off * (VEC / 4);
+#pragma unroll
+            for (int i = 0; i < VEC / 4; ++i) dst[i] = word[i];
+          }
+        } else if (sp.errors) {
           const raw_t packed = E::pack(o);  // rounds to the storage type exactly as the written tensor would be
           float r[VEC];
           E::unpack(packed, r);
@@ -1550,7 +1567,9 @@ __global__ __launch_bounds__(256) void smooth_int_kernel(const SmoothParams sp) 
           out[g * raws_per_group + off] = E::pack(o);
         }
       }
-      if (sp.errors) {
+      if (sp.codes) {
+        if (tl == 0 && live) sp.code_scales[static_cast<int64_t>(k) * p.G + g] = sc;
+      } else if (sp.errors) {
         for (int w = TL >> 1; w > 0; w >>= 1) acc = acc + __shfl_xor(acc, w, kWave);
         if (tl == 0 && live) sp.errors[static_cast<int64_t>(k) * p.G + g] = acc;
       }
@@ -1620,17 +1639,49 @@ extern "C" int dcq_selftest_division(const float* x, const float* s, float* fast
   return DCQ_OK;
 }
 
+namespace dcq {
+// the three outputs of the smoothing kernel: the processed tensor (one candidate), the error table, or codes + scales
+static int smooth_entry(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
+                        int64_t groups_per_row, const float* chan_scale, int32_t K, int32_t mode, int32_t has_ratio,
+                        float ratio, void* dequant, float* errors, double degree, const uint16_t* pow_table,
+                        int8_t* codes, float* code_scales, int32_t* nonfinite, dcq_stream_t stream);
+}  // namespace dcq
+
 extern "C" int dcq_smooth_fake_quant_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
                                             int64_t groups_per_row, const float* chan_scale, int32_t K, int32_t mode,
                                             int32_t has_ratio, float ratio, void* dequant, float* errors, double degree,
                                             const uint16_t* pow_table, int32_t* nonfinite, dcq_stream_t stream) {
-  using namespace dcq;
-  DCQ_REQUIRE(step != nullptr, DCQ_ERR_ARGUMENT, "step is NULL");
-  DCQ_REQUIRE(G >= 0 && S > 0 && groups_per_row > 0 && K > 0, DCQ_ERR_ARGUMENT, "bad sizes");
-  DCQ_REQUIRE(mode == 0 || mode == 1, DCQ_ERR_ARGUMENT, "mode must be 0 (multiply first) or 1 (divide first)");
   DCQ_REQUIRE((dequant != nullptr) != (errors != nullptr), DCQ_ERR_ARGUMENT,
               "exactly one of the processed tensor and the error table is written");
   DCQ_REQUIRE(dequant == nullptr || K == 1, DCQ_ERR_ARGUMENT, "the processed tensor is written for one candidate");
+  return dcq::smooth_entry(step, x, storage, G, S, groups_per_row, chan_scale, K, mode, has_ratio, ratio, dequant, errors,
+                           degree, pow_table, nullptr, nullptr, nonfinite, stream);
+}
+
+extern "C" int dcq_smooth_quantize_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
+                                          int64_t groups_per_row, const float* chan_scale, int32_t K, int32_t mode,
+                                          int32_t has_ratio, float ratio, int8_t* codes, float* scales,
+                                          int32_t* nonfinite, dcq_stream_t stream) {
+  DCQ_REQUIRE(G == 0 || (codes != nullptr && scales != nullptr), DCQ_ERR_ARGUMENT, "NULL buffer");
+  DCQ_REQUIRE(step != nullptr, DCQ_ERR_ARGUMENT, "step is NULL");
+  // the stored byte is the integer the scale multiplies: it has to fit, and a zero point has to live in its domain
+  DCQ_REQUIRE(step->zero_domain != DCQ_ZERO_POST_SCALE, DCQ_ERR_UNSUPPORTED,
+              "a zero point subtracted after the scale leaves no integer code");
+  const bool pre = step->zero_domain == DCQ_ZERO_PRE_SCALE;
+  const float top = step->tensor.hi - (pre ? step->zero.lo : 0.0f), bottom = step->tensor.lo - (pre ? step->zero.hi : 0.0f);
+  DCQ_REQUIRE(top <= 127.0f && bottom >= -128.0f, DCQ_ERR_UNSUPPORTED, "code minus zero point does not fit a signed byte");
+  return dcq::smooth_entry(step, x, storage, G, S, groups_per_row, chan_scale, K, mode, has_ratio, ratio, nullptr, nullptr,
+                           2.0, nullptr, codes, scales, nonfinite, stream);
+}
+
+namespace dcq {
+static int smooth_entry(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
+                        int64_t groups_per_row, const float* chan_scale, int32_t K, int32_t mode, int32_t has_ratio,
+                        float ratio, void* dequant, float* errors, double degree, const uint16_t* pow_table,
+                        int8_t* codes, float* code_scales, int32_t* nonfinite, dcq_stream_t stream) {
+  DCQ_REQUIRE(step != nullptr, DCQ_ERR_ARGUMENT, "step is NULL");
+  DCQ_REQUIRE(G >= 0 && S > 0 && groups_per_row > 0 && K > 0, DCQ_ERR_ARGUMENT, "bad sizes");
+  DCQ_REQUIRE(mode == 0 || mode == 1, DCQ_ERR_ARGUMENT, "mode must be 0 (multiply first) or 1 (divide first)");
   if (G == 0) return DCQ_OK;
   DCQ_REQUIRE(x && chan_scale, DCQ_ERR_ARGUMENT, "NULL buffer");
   const dcq_step& st = *step;
@@ -1676,6 +1727,8 @@ extern "C" int dcq_smooth_fake_quant_groups(const dcq_step* step, const void* x,
   sp.divide_first = mode;
   sp.K = K;
   sp.errors = errors;
+  sp.codes = codes;
+  sp.code_scales = code_scales;
   sp.degree = static_cast<float>(degree);
   sp.table = nullptr;
   if (errors != nullptr && storage != DCQ_F32 && round_degree_to_storage(degree, storage) != 2.0) {
@@ -1695,3 +1748,4 @@ extern "C" int dcq_smooth_fake_quant_groups(const dcq_step* step, const void* x,
       return DCQ_ERR_ARGUMENT;
   }
 }
+}  // namespace dcq

@@ -550,6 +550,67 @@ def smooth_fake_quant(step: Step, x: torch.Tensor, groups_per_row: int, chan_sca
     return out if errors is None else errors
 
 
+def smooth_codes_are_fusable(step: Step) -> bool:
+    """Whether ``dcq_smooth_quantize_groups`` covers this step: fusable, and the integer its scale multiplies (the
+    code, minus a zero point of the code's domain) fits a signed byte."""
+    if not smooth_step_is_fusable(step) or step.zero_domain == _lib.ZERO_POST:
+        return False
+    pre = step.zero_domain == _lib.ZERO_PRE
+    top = step.tensor.hi - (step.zero.lo if pre else 0.0)
+    bottom = step.tensor.lo - (step.zero.hi if pre else 0.0)
+    return top <= 127.0 and bottom >= -128.0
+
+
+def smooth_quantize(step: Step, x: torch.Tensor, groups_per_row: int, chan_scale: torch.Tensor, *,
+                    divide_first: bool, ratio: float | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """x[G][S] and chan_scale [K][C] float32 -> (int8 codes [K][G][S], float32 scales [K][G]) of every smoothing
+    candidate: the integers and group scales whose product, smoothed back, is what ``smooth_fake_quant`` writes."""
+    _require_gpu(x)
+    assert x.ndim == 2 and x.is_contiguous()
+    G, S = x.shape
+    cs = chan_scale.to(device=x.device, dtype=torch.float32).contiguous().view(-1, groups_per_row * S)
+    K = cs.shape[0]
+    codes = torch.empty((K, G, S), dtype=torch.int8, device=x.device)
+    scales = torch.empty((K, G), dtype=torch.float32, device=x.device)
+    check(lib().dcq_smooth_quantize_groups(C.byref(step), ptr(x), storage_of(x.dtype), G, S, groups_per_row, ptr(cs), K,
+                                           1 if divide_first else 0, 0 if ratio is None else 1,
+                                           0.0 if ratio is None else float(ratio), ptr(codes), ptr(scales),
+                                           _nonfinite_ptr(), stream_of(x.device)), "dcq_smooth_quantize_groups")
+    return codes, scales
+
+
+def linear_candidate_errors(x_codes: torch.Tensor, x_scales: torch.Tensor, w_codes: torch.Tensor,
+                            w_scales: torch.Tensor, bias: torch.Tensor | None, target: torch.Tensor,
+                            out: torch.Tensor | None = None) -> torch.Tensor:
+    """Codes [K][T][C] / [K][R][C] (int8) with their group scales [K][T][gx] / [K][R][gw] and the outputs to match
+    [T][R] -> float64 [K]: sum over the outputs of (x' w'^T + bias - target)^2 per candidate, added to ``out`` when
+    given (``dcq_linear_candidate_errors``)."""
+    _require_gpu(x_codes)
+    K, T, Cn = x_codes.shape
+    R = w_codes.shape[1]
+    assert w_codes.shape == (K, R, Cn) and x_codes.dtype == torch.int8 and w_codes.dtype == torch.int8
+    assert x_codes.is_contiguous() and w_codes.is_contiguous() and x_scales.is_contiguous() and w_scales.is_contiguous()
+    assert x_scales.dtype == torch.float32 and w_scales.dtype == torch.float32
+    gx, gw = x_scales.numel() // (K * T), w_scales.numel() // (K * R)
+    assert x_scales.numel() == K * T * gx and w_scales.numel() == K * R * gw and Cn % gx == 0 and Cn % gw == 0
+    assert target.is_cuda and target.dtype == torch.float32 and target.shape == (T, R) and target.stride(1) == 1
+    if bias is not None:
+        bias = bias.to(device=x_codes.device, dtype=torch.float32).contiguous()
+        assert bias.numel() == R
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty(K, dtype=torch.float64, device=x_codes.device)
+    assert out.dtype == torch.float64 and out.numel() == K and out.is_contiguous()
+    need = lib().dcq_linear_candidate_errors_workspace(T, R, K)
+    work = torch.empty(max(need, 8), dtype=torch.uint8, device=x_codes.device)
+    check(lib().dcq_linear_candidate_errors(ptr(x_codes), ptr(x_scales), T, Cn // gx, ptr(w_codes), ptr(w_scales), R,
+                                            Cn // gw, Cn, K, ptr(bias), C.c_void_p(target.data_ptr()), target.stride(0),
+                                            ptr(work), need,
+                                            ptr(out), int(accumulate), stream_of(x_codes.device)),
+          "dcq_linear_candidate_errors")
+    return out
+
+
 def group_error(a: torch.Tensor, b: torch.Tensor, degree: float) -> torch.Tensor:
     """a, b [G][S] of one dtype -> float32 [G]: sum over each group of |a - b|^degree evaluated in that dtype,
     accumulated in float32 and not rounded back."""

@@ -360,16 +360,19 @@ class QuantizerImpl:
     def smooth_candidates(self, tensor: torch.Tensor, chan_scale: torch.Tensor, *, divide_first: bool,
                           channels_dim: int | None = None, scale=None, zero=None, dynamic_range=None,
                           range_bound: RangeBound | None = None, quant_range: QuantRange | None = None,
-                          default_dtype: torch.dtype | None = None, errors_degree: float | None = None
-                          ) -> torch.Tensor | None:
+                          default_dtype: torch.dtype | None = None, errors_degree: float | None = None,
+                          as_codes: bool = False) -> torch.Tensor | tuple[torch.Tensor, torch.Tensor] | None:
         """A smoothing candidate through the fused kernel (reference op chain: calib/smooth.py:504-530).
 
         ``chan_scale`` [C]: returns ``Q(tensor * s) / s`` (or ``Q(tensor / s) * s`` with ``divide_first``) in the
         tensor's dtype, equal bit for bit to scaling in float32, ``quantize`` and scaling back.  ``chan_scale``
         [K][C] with ``errors_degree``: returns the float32 [K][#groups] error sums |processed - tensor|^degree of all
-        K candidates from one read of the tensor.  Returns None when the configuration is outside the fused kernel
-        (several steps or scale levels, non-integer types, fixed scales or ranges, groups that are not runs of
-        channels inside one row): the caller then takes the general path."""
+        K candidates from one read of the tensor.  ``chan_scale`` [K][C] with ``as_codes``: returns the int8 codes
+        [K][rows][C] (minus the zero point, when it lives in the code's domain) and float32 group scales
+        [K][rows][#groups per row] whose product is the fake-quantized smoothed tensor of every candidate.  Returns
+        None when the configuration is outside the fused kernel (several steps or scale levels, non-integer types,
+        fixed scales or ranges, groups that are not runs of channels inside one row): the caller then takes the
+        general path."""
         if not tensor.is_cuda or not tensor.is_contiguous():
             return None
         shape = tensor.shape
@@ -404,6 +407,12 @@ class QuantizerImpl:
         if group % vec or chan_scale.shape[-1] != groups_per_row * group or tensor.data_ptr() % 16:
             return None
         x2d = tensor.view(rows * groups_per_row, group)
+        if as_codes:
+            if not engine.smooth_codes_are_fusable(step):
+                return None
+            codes, scales = engine.smooth_quantize(step, x2d, groups_per_row, chan_scale, divide_first=divide_first,
+                                                   ratio=ratio)
+            return codes.view(-1, rows, groups_per_row * group), scales.view(-1, rows, groups_per_row)
         out = engine.smooth_fake_quant(step, x2d, groups_per_row, chan_scale, divide_first=divide_first, ratio=ratio,
                                        errors_degree=errors_degree)
         return out.view(shape) if errors_degree is None else out

@@ -126,8 +126,8 @@ class Quantizer(QuantizerImpl):
             develop_dtype=pick(develop_dtype, self.develop_dtype), **kwargs)
 
     def smooth_candidates(self, tensor: torch.Tensor, chan_scale: torch.Tensor, *, divide_first: bool,
-                          channels_dim=MISSING, default_dtype=MISSING, errors_degree: float | None = None
-                          ) -> torch.Tensor | None:
+                          channels_dim=MISSING, default_dtype=MISSING, errors_degree: float | None = None,
+                          as_codes: bool = False) -> torch.Tensor | tuple[torch.Tensor, torch.Tensor] | None:
         """``QuantizerImpl.smooth_candidates`` with this quantizer's own scale / zero / ranges (round-to-nearest: the
         searches never use another kernel, calib/smooth.py:526-528).  None = not covered by the fused kernel."""
         pick = lambda given, own: own if given is MISSING else given  # noqa: E731
@@ -137,7 +137,7 @@ class Quantizer(QuantizerImpl):
             tensor, chan_scale, divide_first=divide_first, channels_dim=pick(channels_dim, self.channels_dim),
             scale=self.scale, zero=self.zero, dynamic_range=self.dynamic_range, range_bound=self.range_bound,
             quant_range=self.quant_range, default_dtype=pick(default_dtype, self.default_dtype),
-            errors_degree=errors_degree)
+            errors_degree=errors_degree, as_codes=as_codes)
 
     def update(self, tensor_shape: torch.Size, default_dtype: torch.dtype | _MISSING_TYPE = MISSING,
                quant_range: QuantRange | None | _MISSING_TYPE = MISSING,

@@ -424,6 +424,37 @@ int dcq_smooth_fake_quant_groups(const dcq_step* step, const void* x, int32_t st
                                  int32_t has_ratio, float ratio, void* dequant, float* errors, double degree,
                                  const uint16_t* pow_table, int32_t* nonfinite, dcq_stream_t stream);
 
+/* dcq_smooth_quantize_groups: the same candidates (same arguments, same arithmetic up to the rounded code), but what
+ * is written is what the GEMM below multiplies: codes[k][g][i] (int8) = the integer that the group's scale
+ * multiplies -- the code, minus the zero point when the zero point lives in the code's domain -- and
+ * scales[k][g] (float32) = the group's scale, for every candidate k.  The fake-quantized tensor of candidate k is
+ * codes * scales, times (mode 1) or divided by (mode 0) chan_scale[k].  DCQ_ERR_UNSUPPORTED when the zero point is
+ * applied after the scale, or code minus zero point can leave [-128, 127].
+ *
+ * dcq_linear_candidate_errors: K smoothing candidates of ONE linear module scored on its outputs (the OutputsError
+ * objective when the evaluated module is the linear itself, calib/search.py:1011-1042 with smooth.py:575-625 putting
+ * the candidate in place):
+ *     errors[k] (+)= sum_{t, r} ( sum_c X'_k[t][c] W'_k[r][c] + bias[r] - target[t][r] )^2
+ * with X'_k = Q(x / s_k) * s_k and W'_k = Q(w * s_k) / s_k given by their codes and group scales (x_codes [K][T][C],
+ * x_scales [K][T][C / x_group], w_codes [K][R][C], w_scales [K][R][C / w_group]); s_k cancels in every product, so
+ * the inner sums run over int8 codes on the matrix cores, exact in int32, and are scaled per (token group, row group)
+ * in float32.  The reference multiplies the float32 processed tensors instead: both agree up to the float32
+ * rounding of the processed values.  target [T][ld_target] holds the outputs to match (bias included); bias may be
+ * NULL.  errors [K] is float64; accumulate != 0 adds to it (a list of batches is scored by calling once per batch).
+ * C must be a multiple of 16; groups that are shorter than a row must be multiples of 128 channels with one size a
+ * multiple of the other.  workspace: dcq_linear_candidate_errors_workspace(T, R, K) bytes. */
+int dcq_smooth_quantize_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
+                               int64_t groups_per_row, const float* chan_scale, int32_t K, int32_t mode,
+                               int32_t has_ratio, float ratio, int8_t* codes, float* scales, int32_t* nonfinite,
+                               dcq_stream_t stream);
+
+int64_t dcq_linear_candidate_errors_workspace(int64_t T, int64_t R, int32_t K);
+
+int dcq_linear_candidate_errors(const int8_t* x_codes, const float* x_scales, int64_t T, int64_t x_group,
+                                const int8_t* w_codes, const float* w_scales, int64_t R, int64_t w_group, int64_t C,
+                                int32_t K, const float* bias, const float* target, int64_t ld_target, void* workspace,
+                                int64_t workspace_bytes, double* errors, int32_t accumulate, dcq_stream_t stream);
+
 int dcq_channel_metric(const void* x, int32_t storage, int64_t N, int64_t C, int64_t inner, int32_t mode, float* out_max,
                        double* out_sum, dcq_stream_t stream);
 
