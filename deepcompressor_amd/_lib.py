@@ -159,5 +159,13 @@ def ptr(t: torch.Tensor | None):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_of(device: torch.device):
+    """The HIP stream torch currently launches on for ``device`` (the raw handle: building a ``torch.cuda.Stream``
+    object per call costs several microseconds)."""
+    if _raw_stream is not None:
+        index = device.index
+        return C.c_void_p(_raw_stream(torch.cuda.current_device() if index is None else index))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

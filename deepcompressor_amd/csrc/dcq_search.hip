@@ -97,6 +97,15 @@ __device__ __forceinline__ float row_shift_right1(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
 }
 
+// sum over each team of 8 lanes, every lane gets it (quad swaps, then the mirror of each half row); the order of the
+// additions is not the reference's: for bounds only
+__device__ __forceinline__ float team8_sum_any_order(float v) {
+  v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  return v;
+}
+
 template <int ST, int NPL, int ZD, int POW, bool INT_Q>
 __global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const SearchParams p) {
   constexpr int kSearchBlock = search_block(NPL);
@@ -191,6 +200,13 @@ __global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const S
     }
     float best_err = 0.0f;
     int best_k = 0;
+    // Candidates that cannot win are dropped part-way (only the best candidate of a group is wanted unless the error
+    // table is): every term of the sum is >= 0 and float addition is monotone, so the sum over a quarter / a half of
+    // the elements, made a little smaller than any summation order could round it, is a lower bound of the candidate's
+    // error; once that is at least one unit in the last place of the storage type above the group's best, the rounded
+    // error cannot be smaller than the best (ties go to the earlier candidate anyway).  The wave moves on when all of
+    // its 8 groups say so.  The winner and its error are those of the full evaluation.
+    const bool prune = PACKED && p.errors == nullptr;
     // The scale, zero point and reciprocal of a candidate are the same for the 8 lanes of a group: lane j works them
     // out for candidate k0 + j, and the team then takes the candidates of the batch one by one from the lane that
     // holds them (LDS-crossbar permute), instead of every lane repeating the ~40 instructions for every candidate.
@@ -228,8 +244,20 @@ __global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const S
           done = true;
           const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(mine_y)));
           const f32x2 z2 = {sz.z, sz.z}, s2 = {sz.s, sz.s};
+          float seen = 0.0f;  // sum of the terms so far, in any order
+          bool dropped = false;
 #pragma unroll
           for (int i = 0; i < NPL; i += 2) {
+            if (NPL >= 8 && (i == NPL / 4 || i == NPL / 2) && prune && k > 0) {
+#pragma unroll
+              for (int m = (i == NPL / 4 ? 0 : NPL / 4); m < i; ++m) seen = seen + pw[m];
+              const float lower = team8_sum_any_order(seen) * (1.0f - 0x1p-20f);
+              const bool may_win = j == kTeam - 1 && lower < best_err * (1.0f + 0x1p-7f);
+              if (__builtin_amdgcn_ballot_w64(may_win) == 0) {
+                dropped = true;
+                break;
+              }
+            }
             const f32x2 xv = {x[i], x[i + 1]};
             f32x2 t = ZD == DCQ_ZERO_POST_SCALE ? xv + z2 : xv;
             t = div_hoisted2(t, sz.s, y);
@@ -256,6 +284,7 @@ __global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const S
               pw[i + 1] = sq.y;
             }
           }
+          if (dropped) continue;
         }
       }
 #pragma unroll

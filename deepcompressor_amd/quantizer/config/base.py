@@ -175,6 +175,16 @@ class ProgressiveQuantizerConfig(QuantizerConfig):
             return DecomposedQuantizerConfig(steps=())
         if not self.intermediate_dtypes:
             return DecomposedQuantizerConfig(steps=(self,))
+        # (called once per quantize(): the step configs are rebuilt only when a field changed)
+        key = (self.dtype, self.zero_point, self.group_shapes, self.scale_dtypes, self.intermediate_dtypes,
+               self.intermediate_levels, self.needs_dequant_saturation)
+        memo = self.__dict__.get("_decomposed")
+        if memo is not None and memo[0] == key:
+            return memo[1]
+        self.__dict__["_decomposed"] = (key, self._decompose_steps())
+        return self.__dict__["_decomposed"][1]
+
+    def _decompose_steps(self) -> DecomposedQuantizerConfig:
         steps, first = [], 0
         for level, dtype in zip(self.intermediate_levels, self.intermediate_dtypes, strict=True):
             steps.append(QuantizerConfig(dtype=dtype, zero_point=None, group_shapes=self.group_shapes[first : level + 1],

@@ -23,10 +23,10 @@ for policy in ("deferred", "always"):
 if len(sys.argv) > 1:
     import cProfile, pstats
     engine.FINITE_CHECKS = "deferred"
-    q = build_quantizer(FQ.meta["cases"]["uint4_post_g128_f16s"])
+    q = build_quantizer(FQ.meta["cases"][sys.argv[1] if sys.argv[1] in FQ.meta["cases"] else "uint4_post_g128_f16s"])
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(2000):
         q.quantize(x)
     pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
