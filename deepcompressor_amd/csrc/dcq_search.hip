@@ -22,11 +22,16 @@ constexpr int kTeam = 8;                       // lanes per group = SIMD width o
 constexpr int kGroupsPerWave = kWave / kTeam;  // 8
 constexpr int kTableEntries = 32768;
 
-// Threads per block by values per lane: 16 waves share one 64 KiB table per CU while the registers
-// allow it (<= 128 VGPRs at 16 elements per lane); longer groups trade waves for registers and LDS.
-constexpr int search_block(int npl) { return npl <= 16 ? 1024 : (npl == 32 ? 512 : 256); }
-
 enum PowMode { kPowTable = 0, kPowSquare = 1, kPowFloat = 2 };
+
+// Threads per block by values per lane.  With the power table: 16 waves share one 64 KiB table per CU while the
+// registers allow it (<= 128 VGPRs at 16 elements per lane); longer groups trade waves for registers and LDS.
+// Without it nothing is shared, and four-wave workgroups (the same waves per SIMD) find room on a CU that other
+// streams' kernels occupy in part, where a 16-wave workgroup waits for a CU to drain completely.
+constexpr int search_block(int npl, int pow_mode) {
+  return pow_mode != kPowTable ? 256 : (npl <= 16 ? 1024 : (npl == 32 ? 512 : 256));
+}
+constexpr int search_waves_per_simd(int npl) { return npl <= 16 ? 4 : (npl == 32 ? 2 : 1); }
 
 struct SearchParams {
   dcq_step step;
@@ -107,8 +112,9 @@ __device__ __forceinline__ float team8_sum_any_order(float v) {
 }
 
 template <int ST, int NPL, int ZD, int POW, bool INT_Q>
-__global__ __launch_bounds__(search_block(NPL)) void range_search_kernel(const SearchParams p) {
-  constexpr int kSearchBlock = search_block(NPL);
+__global__ __launch_bounds__(search_block(NPL, POW), search_waves_per_simd(NPL)) void range_search_kernel(
+    const SearchParams p) {
+  constexpr int kSearchBlock = search_block(NPL, POW);
   constexpr int kGroupsPerBlock = kSearchBlock / kTeam;
   using St = Storage<ST>;
   using elem_t = typename St::elem_t;
@@ -500,12 +506,13 @@ double round_degree_to_storage(double degree, int storage) {
 template <int ST, int NPL, int ZD, int POW>
 static int launch_search(const SearchParams& p, hipStream_t stream) {
   constexpr int EB = sizeof(typename Storage<ST>::elem_t);
-  constexpr int kSearchBlock = search_block(NPL);
+  constexpr int kSearchBlock = search_block(NPL, POW);
   constexpr int kGroupsPerBlock = kSearchBlock / kTeam;
   // dynamic part (the kernel's power table is static)
   const size_t lds = 3 * 256 * 4 + static_cast<size_t>(kSearchBlock / kWave) * kGroupsPerWave * (NPL * kTeam * EB + 16);
   int64_t blocks = (p.G + kGroupsPerBlock - 1) / kGroupsPerBlock;
-  if (blocks > 256) blocks = 256;
+  const int64_t most = 256 * (16 * kWave / kSearchBlock) * search_waves_per_simd(NPL) / 4;  // the chip's worth of waves
+  if (blocks > most) blocks = most;
   const bool int_q = p.step.tensor.kind == DCQ_ROUND_INT;
   auto kern = int_q ? range_search_kernel<ST, NPL, ZD, POW, true> : range_search_kernel<ST, NPL, ZD, POW, false>;
   if (lds > 64 * 1024) {
