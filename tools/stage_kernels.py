@@ -14,6 +14,8 @@ import torch.nn as nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
+bench.torch = torch  # (bench imports torch inside main(), which this program does not run)
+
 from deepcompressor_amd.calib import calibrate_dynamic_range  # noqa: E402
 from deepcompressor_amd.data.common import TensorType  # noqa: E402
 
