@@ -194,7 +194,7 @@ class DynamicRangeCalibrator:
             return
         errors = self._reduce(out["errors"].view(len(ratios), *view[::2]), w.dtype)  # [K, *error_shape]
         self.best_error, first = _first_strict_min(errors)
-        r32 = torch.tensor(ratios, dtype=torch.float64).to(torch.float32).to(w.device)
+        r32 = engine._device_ratios(tuple(ratios), w.device)
         self.base_range = DynamicRange.construct(
             w.view(view), zero_domain=q_zero_domain(self.quantizer),
             is_float_point=self.quantizer.config.quant_dtype.is_float_point)

@@ -466,6 +466,21 @@ def pow_table(device: torch.device, dtype: torch.dtype, degree: float) -> torch.
     return table
 
 
+_ratio_lists: dict[tuple, torch.Tensor] = {}
+
+
+def _device_ratios(ratios: tuple, device: torch.device) -> torch.Tensor:
+    """The candidate ratios as a float32 device vector, kept per (list, device): every linear of a stage searches the
+    same list, and a copy from pageable host memory waits for the work already queued on the stream."""
+    key = (ratios, device)
+    r = _ratio_lists.get(key)
+    if r is None:
+        if len(_ratio_lists) > 64:
+            _ratio_lists.clear()
+        r = _ratio_lists[key] = torch.tensor(ratios, dtype=torch.float64).to(torch.float32).to(device)
+    return r
+
+
 def range_search_groups(step: Step, w: torch.Tensor, ratios: list[float], degree: float, *, want_errors=False,
                         unrounded_errors=False):
     """w[G][S] -> dict(max, min | None, ratio, error[, errors[K][G]]) of float32 tensors.  ``errors`` holds the
@@ -473,7 +488,7 @@ def range_search_groups(step: Step, w: torch.Tensor, ratios: list[float], degree
     _require_gpu(w)
     G, S = w.shape
     dev = w.device
-    r = torch.tensor(ratios, dtype=torch.float64).to(torch.float32).to(dev)
+    r = _device_ratios(tuple(ratios), dev)
     zp = step.zero_domain != _lib.ZERO_NONE
     out = dict(max=_f32(G, dev), min=_f32(G, dev) if zp else None, ratio=_f32(G, dev), error=_f32(G, dev))
     errors = torch.empty((len(ratios), G), dtype=torch.float32, device=dev) if want_errors else None
