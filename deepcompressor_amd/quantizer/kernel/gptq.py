@@ -88,6 +88,7 @@ _state = _State()
 # ``clear_hessian_cache``; read-only once stored.
 _prepared: dict = {}  # key -> (activation tensors held alive, Hessian)
 _prepared_lock = threading.Lock()
+PREPARED_LIMIT = 16  # prepared Hessians kept at most (oldest dropped first): a caller that never clears stays bounded
 
 
 def clear_hessian_cache() -> None:
@@ -103,7 +104,8 @@ def prepare_hessians(caches, device: torch.device, world: int = 1, round_width: 
     """Compute the Hessian of every activation cache in ``caches`` now, one after the other on the current stream
     (each launch has the whole chip), and keep them for ``hessian_of`` calls from any thread until
     ``clear_hessian_cache`` -- call that when the layer is done: every entry holds its cache's activation tensors
-    alive (multi-GB at the calibration sizes of a language model).  The pipelines that consume the Hessians (inverse
+    alive (multi-GB at the calibration sizes of a language model; at most ``PREPARED_LIMIT`` entries are kept, the
+    oldest go first).  The pipelines that consume the Hessians (inverse
     factor, sweeps) are latency-bound and may then run concurrently on several streams without slowing the
     matrix-core SYRKs down.
 
@@ -134,6 +136,8 @@ def prepare_hessians(caches, device: torch.device, world: int = 1, round_width: 
                 hit = _compute_hessian(inputs, device, round_width=round_width, profile_events=events)
             with _prepared_lock:
                 _prepared[key] = (tuple(inputs.data), hit)
+                while len(_prepared) > PREPARED_LIMIT:
+                    _prepared.pop(next(iter(_prepared)))
         out.append(hit)
     return out
 
