@@ -183,7 +183,11 @@ template <bool A_KMAJOR, int T>
 __global__ __launch_bounds__(kGemmThreads, 4) void gemm_f32_kernel(const GemmParams p) {
   extern __shared__ __align__(16) unsigned char gemm_smem[];
   float* lds = reinterpret_cast<float*>(gemm_smem);  // [buffer][A | B][k][m or n]
-  const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+  int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+  // triangular operands: the tiles with the longest reductions are dispatched first (largest m when k <= m, largest
+  // n when k <= n; k >= m already has them first), so the launch does not end on a few full-length tiles
+  if (p.k_below_m) tm = p.tiles_m - 1 - tm;
+  if (p.k_below_n) tn = p.tiles_n - 1 - tn;
   if (p.upper_only && tn < tm) return;
   constexpr int kGK = GemmStep<T>::value;
   const int m0 = tm * T, n0 = tn * T;
@@ -410,7 +414,9 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
 template <bool A_KMAJOR>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(const GemmParams p) {
   extern __shared__ __align__(16) unsigned char gemm_smem[];
-  const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+  int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+  if (p.k_below_m) tm = p.tiles_m - 1 - tm;  // longest reductions first (see gemm_f32_kernel)
+  if (p.k_below_n) tn = p.tiles_n - 1 - tn;
   if (p.upper_only && tn < tm) return;
   const int m0 = tm * 128, n0 = tn * 128;
   int k_begin = 0, k_end = p.K;
