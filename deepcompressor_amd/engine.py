@@ -204,13 +204,15 @@ def _f32(n, device) -> torch.Tensor:
 # kernel calls
 # ---------------------------------------------------------------------------------------------
 def fake_quant_fused(step: Step, x: torch.Tensor, *, range_max=None, range_min=None, ratio=None, want_dequant=True,
-                     want_codes=False):
-    """x[G][S] -> (dequant | None, codes | None, scale[G], zero[G])."""
+                     want_codes=False, want_scales=True):
+    """x[G][S] -> (dequant | None, codes | None, scale[G], zero[G]).  ``want_scales`` False: the per-group scales and
+    zeros are not written (and returned as None): a caller that only takes the fake-quantized tensor saves their
+    buffers and, for short groups, a noticeable share of the pass's writes (8 bytes per group)."""
     _require_gpu(x)
     G, S = x.shape
     dq = torch.empty_like(x) if want_dequant else None
     codes = torch.empty((G, S), dtype=torch.float32, device=x.device) if want_codes else None
-    scale, zero = _f32(G, x.device), _f32(G, x.device)
+    scale, zero = (_f32(G, x.device), _f32(G, x.device)) if want_scales else (None, None)
     check(lib().dcq_fake_quant_groups(C.byref(step), ptr(x), storage_of(x.dtype), G, S, ptr(range_max), ptr(range_min),
                                       int(ratio is not None), float(ratio or 0.0), ptr(dq), ptr(codes), ptr(scale),
                                       ptr(zero), _nonfinite_ptr(), stream_of(x.device)), "dcq_fake_quant_groups")
@@ -219,15 +221,15 @@ def fake_quant_fused(step: Step, x: torch.Tensor, *, range_max=None, range_min=N
 
 def fake_quant_fused_outer(step: Step, x: torch.Tensor, outer: torch.Tensor, outer_lo: float, outer_hi: float, *,
                            deq_clamp: bool, deq_lo: float, deq_hi: float, range_max=None, range_min=None, ratio=None,
-                           out_dtype=None, want_dequant=True, want_codes=False):
+                           out_dtype=None, want_dequant=True, want_codes=False, want_scales=True):
     """Last step of a progressive quantizer in one pass: x[G][S], outer[G] (the previous steps' scale per group)
-    -> (dequant | None, codes | None, scale[G], zero[G])."""
+    -> (dequant | None, codes | None, scale[G] | None, zero[G] | None)."""
     _require_gpu(x)
     G, S = x.shape
     out_dtype = out_dtype or x.dtype
     dq = torch.empty((G, S), dtype=out_dtype, device=x.device) if want_dequant else None
     codes = torch.empty((G, S), dtype=torch.float32, device=x.device) if want_codes else None
-    scale, zero = _f32(G, x.device), _f32(G, x.device)
+    scale, zero = (_f32(G, x.device), _f32(G, x.device)) if want_scales else (None, None)
     check(lib().dcq_fake_quant_groups_outer(C.byref(step), ptr(x), storage_of(x.dtype), G, S, ptr(outer), float(outer_lo),
                                             float(outer_hi), int(deq_clamp), float(deq_lo), float(deq_hi),
                                             ptr(range_max), ptr(range_min), int(ratio is not None), float(ratio or 0.0),
@@ -257,15 +259,16 @@ def progressive_is_fusable(first: Step, last: Step, row_len: int, group: int, dt
 
 def fake_quant_progressive(first: Step, last: Step, x: torch.Tensor, group: int, outer_lo: float, outer_hi: float, *,
                            deq_clamp: bool, deq_lo: float, deq_hi: float, first_ratio=None, ratio=None,
-                           want_dequant=True, want_codes=False):
+                           want_dequant=True, want_codes=False, want_scales=True):
     """Both steps of a two-step quantizer in one pass: x[rows][row_len] -> (dequant | None, codes | None,
-    first_scale[rows], scale[G], zero[G]) with G = rows * row_len / group."""
+    first_scale[rows], scale[G] | None, zero[G] | None) with G = rows * row_len / group."""
     _require_gpu(x)
     rows, row_len = x.shape
     G = rows * (row_len // group)
     dq = torch.empty_like(x) if want_dequant else None
     codes = torch.empty((rows, row_len), dtype=torch.float32, device=x.device) if want_codes else None
-    s0, scale, zero = _f32(rows, x.device), _f32(G, x.device), _f32(G, x.device)
+    s0 = _f32(rows, x.device)
+    scale, zero = (_f32(G, x.device), _f32(G, x.device)) if want_scales else (None, None)
     check(lib().dcq_fake_quant_progressive(
         C.byref(first), C.byref(last), ptr(x), storage_of(x.dtype), rows, row_len, group, int(first_ratio is not None),
         float(first_ratio or 0.0), int(ratio is not None), float(ratio or 0.0), float(outer_lo), float(outer_hi),
@@ -275,14 +278,15 @@ def fake_quant_progressive(first: Step, last: Step, x: torch.Tensor, group: int,
 
 
 def fake_quant_two_level(step: Step, level0: Rounding, level0_span: float, x: torch.Tensor, *, ratio=None,
-                         want_dequant=True, want_codes=False):
-    """Two scale levels, the first per tensor: x[G][S] -> (dequant | None, codes | None, level0[1], level1[G],
-    compound scale[G])."""
+                         want_dequant=True, want_codes=False, want_scales=True):
+    """Two scale levels, the first per tensor: x[G][S] -> (dequant | None, codes | None, level0[1], level1[G] | None,
+    compound scale[G] | None)."""
     _require_gpu(x)
     G, S = x.shape
     dq = torch.empty_like(x) if want_dequant else None
     codes = torch.empty((G, S), dtype=torch.float32, device=x.device) if want_codes else None
-    top, first, second, scale = _f32(1, x.device), _f32(1, x.device), _f32(G, x.device), _f32(G, x.device)
+    top, first = _f32(1, x.device), _f32(1, x.device)
+    second, scale = (_f32(G, x.device), _f32(G, x.device)) if want_scales else (None, None)
     check(lib().dcq_fake_quant_groups_two_level(C.byref(step), C.byref(level0), float(level0_span), ptr(x),
                                                 storage_of(x.dtype), G, S, int(ratio is not None), float(ratio or 0.0),
                                                 ptr(top), ptr(dq), ptr(codes), ptr(first), ptr(second), ptr(scale),

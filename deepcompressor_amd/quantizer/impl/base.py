@@ -181,8 +181,9 @@ class QuantizerImpl:
         # with both outputs requested the reference hands back the *dequantized float32 values* as qdata
         # (its qdata aliases the buffer it dequantizes in place); reproduce that, see QuantTensor docs
         dq, codes, s, z = engine.fake_quant_fused(step, x2d, range_max=rmax, range_min=rmin, ratio=ratio,
-                                                  want_dequant=want_dequant, want_codes=want_quant)
-        scale = QuantScale().append(s.view(keep))
+                                                  want_dequant=want_dequant, want_codes=want_quant,
+                                                  want_scales=want_quant)
+        scale = QuantScale().append(s.view(keep)) if want_quant else None
         zero = None
         if want_quant:  # (a host-to-device copy when there is no zero point: only when the caller wants it)
             zero = z.view(keep) if sinfo.has_zero_point else torch.tensor(0, dtype=torch.float32, device=tensor.device)
@@ -211,7 +212,7 @@ class QuantizerImpl:
         ratio = None if dyn is None else dyn.ratio
         dq, codes, first, second, compound = engine.fake_quant_two_level(
             step, level0, sinfo.linear_scale_quant_spans[0], x2d, ratio=ratio, want_dequant=want_dequant,
-            want_codes=want_quant)
+            want_codes=want_quant, want_scales=want_quant)
         quantized = scale = zero = None
         if want_quant:
             scale = QuantScale().append(first.view([1] * len(view))).append(second.view(keep))
@@ -449,7 +450,7 @@ class QuantizerImpl:
         dq, codes, s0, s1, z1 = engine.fake_quant_progressive(
             step0, step1, tensor, group, outer_range.min, outer_range.max, deq_clamp=info.needs_dequant_saturation,
             deq_lo=first.quant_dtype.min_value, deq_hi=first.quant_dtype.max_value, first_ratio=ratios[0],
-            ratio=ratios[1], want_dequant=want_dequant, want_codes=want_quant)
+            ratio=ratios[1], want_dequant=want_dequant, want_codes=want_quant, want_scales=want_quant)
         quantized = zero = quant_scale = None
         if want_quant:
             keep0, keep1 = [rows, 1, 1, 1], [rows, 1, v1[2], 1]
@@ -500,7 +501,7 @@ class QuantizerImpl:
         dq, codes, s, z = engine.fake_quant_fused_outer(
             step, x2d, outer, outer_range.min, outer_range.max, deq_clamp=clamp, deq_lo=deq_lo, deq_hi=deq_hi,
             range_max=rmax, range_min=rmin, ratio=ratio, out_dtype=dtype, want_dequant=want_dequant,
-            want_codes=want_quant)
+            want_codes=want_quant, want_scales=want_quant)
         quantized = zero = None
         if want_quant:
             quant_scale.append(QuantScale().append(s.view(keep)))
