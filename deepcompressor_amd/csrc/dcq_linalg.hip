@@ -733,8 +733,11 @@ __global__ __launch_bounds__(256) void flip_pad_rows_kernel(const float* src, in
   extern __shared__ float flip_row[];
   const int64_t i = blockIdx.x;
   float* out = dst + i * np;
+  // Only the upper triangle of the destination is ever read (diagonal blocks as a whole, their lower halves masked):
+  // a row is written from the first column of its diagonal block on.
+  const int64_t j_first = i / kNb * kNb;
   if (i >= n) {
-    for (int64_t j = threadIdx.x; j < np; j += 256) out[j] = i == j ? 1.0f : 0.0f;
+    for (int64_t j = j_first + threadIdx.x; j < np; j += 256) out[j] = i == j ? 1.0f : 0.0f;
     return;
   }
   const float* row = src + perm[n - 1 - i] * n;
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(256) void flip_pad_rows_kernel(const float* src, in
     for (int64_t j = threadIdx.x * 4; j < n; j += 256 * 4)
       *reinterpret_cast<float4*>(flip_row + j) = *reinterpret_cast<const float4*>(row + j);
     __syncthreads();
-    for (int64_t j = threadIdx.x * 4; j < np; j += 256 * 4) {
+    for (int64_t j = j_first + threadIdx.x * 4; j < np; j += 256 * 4) {
       float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       if (j < n) {
         const longlong2 lo = *reinterpret_cast<const longlong2*>(perm + (n - 4 - j));
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(256) void flip_pad_rows_kernel(const float* src, in
   }
   for (int64_t j = threadIdx.x; j < n; j += 256) flip_row[j] = row[j];
   __syncthreads();
-  for (int64_t j = threadIdx.x; j < np; j += 256) {
+  for (int64_t j = j_first + threadIdx.x; j < np; j += 256) {
     float v = 0.0f;
     if (j < n) {
       v = flip_row[perm[n - 1 - j]];
@@ -784,7 +787,9 @@ __global__ __launch_bounds__(256) void flip_transpose_kernel(const float* x, int
   for (int k = 0; k < 4; ++k) {
     const int b = ty + 8 * k;
     const int64_t xr = n - 1 - (bj + b), xc = n - 1 - (bi + tx);
-    tile[b][tx] = (xr >= 0 && xc >= 0) ? x[xr * np + xc] : 0.0f;  // tile[b][a]
+    // U is upper triangular: entries with row > column are zero and X is not read for them (its blocks strictly
+    // below the diagonal hold no data)
+    tile[b][tx] = (xr >= 0 && xc >= 0 && bi + tx <= bj + b) ? x[xr * np + xc] : 0.0f;  // tile[b][a]
   }
   __syncthreads();
 #pragma unroll
@@ -792,6 +797,15 @@ __global__ __launch_bounds__(256) void flip_transpose_kernel(const float* x, int
     const int a = ty + 8 * k;
     const int64_t i = bi + a, j = bj + tx;
     if (i < n && j < n) u[i * n + j] = tile[tx][a];
+  }
+}
+
+// zeroes the kNb x kNb diagonal blocks of a square matrix of leading dimension np (one workgroup per block)
+__global__ __launch_bounds__(256) void zero_diagonal_blocks_kernel(float* x, int64_t np) {
+  float* block = x + static_cast<int64_t>(blockIdx.x) * kNb * (np + 1);
+  for (int e = threadIdx.x; e < kNb * kNb / 4; e += 256) {
+    const int r = e / (kNb / 4), c4 = (e % (kNb / 4)) * 4;
+    *reinterpret_cast<float4*>(block + r * np + c4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
 }
 
@@ -1062,8 +1076,10 @@ int cholesky_inverse_upper_on(const float* H, int64_t n, const int64_t* perm, fl
                        dim3(256), 0, s, H, n, perm, diag_add, A, np);
     DCQ_LAUNCH_CHECK("flip_pad_kernel launch");
   }
-  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, s, X, np * np, 0.0f);
-  DCQ_LAUNCH_CHECK("fill_kernel launch");
+  // The inverse is assembled in its upper triangle; triangular operands are read in whole kNb-blocks, so the lower
+  // halves of the diagonal blocks must read as zero.  Nothing ever reads a block strictly below the diagonal.
+  hipLaunchKernelGGL(zero_diagonal_blocks_kernel, dim3(static_cast<unsigned>(c.nblk)), dim3(256), 0, s, X, np);
+  DCQ_LAUNCH_CHECK("zero_diagonal_blocks_kernel launch");
   rc = factor_invert(A, X, T, np, 0, c.nblk, info, s);
   if (rc != DCQ_OK) return rc;
   hipLaunchKernelGGL(flip_transpose_kernel, dim3(static_cast<unsigned>((n + 31) / 32), static_cast<unsigned>((n + 31) / 32)),

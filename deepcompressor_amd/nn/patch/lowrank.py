@@ -53,6 +53,7 @@ def _split_k_f64(a: torch.Tensor, b: torch.Tensor, *, a_transposed: bool = False
 # Below this order the dense symmetric eigensolver is as fast as the block iteration's own small ones
 DIRECT_EIGH_ORDER = 768
 BLOCK = 128  # vectors iterated together (the wanted ones plus a margin that sets the convergence rate)
+FILTER_PASSES = 2  # filter + orthonormalization passes between two Rayleigh-Ritz steps
 
 
 def _orthonormalize(x: torch.Tensor) -> torch.Tensor:
@@ -162,7 +163,7 @@ def _leading_eigenpairs(gram: torch.Tensor, rank: int, tol: float = 1e-9, max_ro
         # more than ~1e7 (the block's condition number must stay inside what Cholesky QR takes)
         gain = lambda lam: math.acosh(1.0 + 2.0 * max(lam - cut, 1e-7 * top) / cut)  # noqa: E731
         degree = int(max(2, min(40, math.ceil(math.log(2e5) / gain(wanted)), math.floor(math.log(2e7) / gain(top)))))
-        for _ in range(2):
+        for _ in range(FILTER_PASSES):
             x = _orthonormalize(_chebyshev_filter(gram, x, degree, cut, top))
     else:
         return dense(original)
