@@ -577,7 +577,7 @@ class SmoothCalibrator:
                 if x_codes is None:
                     return None
                 gx, gw = Cn // x_codes[1].shape[-1], Cn // w_codes[1].shape[-1]
-                if min(gx, gw) < Cn and (max(gx, gw) % min(gx, gw) or min(gx, gw) % 128):
+                if (min(gx, gw) < Cn and (max(gx, gw) % min(gx, gw) or min(gx, gw) % 128)) or min(gx, gw) > (1 << 17):
                     return None
                 total = engine.linear_candidate_errors(x_codes[0], x_codes[1], w_codes[0], w_codes[1], bias,
                                                        y0.to(w.device).reshape(-1, R), out=total)

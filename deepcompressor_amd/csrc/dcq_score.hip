@@ -256,6 +256,8 @@ extern "C" int dcq_linear_candidate_errors(const int8_t* x_codes, const float* x
   DCQ_REQUIRE(ld_target >= R, DCQ_ERR_ARGUMENT, "ld_target is shorter than a row of outputs");
   const int64_t small = x_group < w_group ? x_group : w_group, large = x_group < w_group ? w_group : x_group;
   const bool multi = small < C;
+  // |code x code| <= 2^14: an int32 sum holds 2^17 of them
+  DCQ_REQUIRE(small <= (1 << 17), DCQ_ERR_UNSUPPORTED, "more than 131072 channels between two foldings of the integer sums");
   DCQ_REQUIRE(!multi || (large % small == 0 && small % kScoreStage == 0), DCQ_ERR_UNSUPPORTED,
               "groups inside a row must be multiples of 128 channels, one size a multiple of the other");
   const int64_t tile_rows = kScoreTile;

@@ -442,7 +442,7 @@ int dcq_smooth_fake_quant_groups(const dcq_step* step, const void* x, int32_t st
  * rounding of the processed values.  target [T][ld_target] holds the outputs to match (bias included); bias may be
  * NULL.  errors [K] is float64; accumulate != 0 adds to it (a list of batches is scored by calling once per batch).
  * C must be a multiple of 16; groups that are shorter than a row must be multiples of 128 channels with one size a
- * multiple of the other.  workspace: dcq_linear_candidate_errors_workspace(T, R, K) bytes. */
+ * multiple of the other; at most 131072 channels per group of the finer side (the int32 sums).  workspace: dcq_linear_candidate_errors_workspace(T, R, K) bytes. */
 int dcq_smooth_quantize_groups(const dcq_step* step, const void* x, int32_t storage, int64_t G, int64_t S,
                                int64_t groups_per_row, const float* chan_scale, int32_t K, int32_t mode,
                                int32_t has_ratio, float ratio, int8_t* codes, float* scales, int32_t* nonfinite,
