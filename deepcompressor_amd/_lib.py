@@ -73,12 +73,14 @@ _SIGNATURES = {
     "dcq_hessian_accumulate_ex": [_p, _i32, _i64, _i64, _f, _p, _p, _i64, _i32, _p, _p, _p],
     "dcq_gptq_sweep_block": [C.POINTER(Step), _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _f, _i32, _i32, _i32, _p,
                              _p, _p, _i64, _p],
-    "dcq_gptq_sweep": [C.POINTER(Step), _p, _i64, _i64, _i64, _p, _p, _p, _f, _i32, _i32, _i32, _p, _p, _p, _i32, _p],
+    "dcq_gptq_sweep": [C.POINTER(Step), _p, _i64, _i64, _i64, _p, _p, _p, _f, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _i64,
+                       _p],
     "dcq_nonfinite_flags": [_p, _i64, _p, _p],
     "dcq_gather_columns": [_p, _i32, _i64, _i64, _i64, _p, _p, _p, _i64, _p],
     "dcq_pack_qserve_w4": [_p, _i64, _i64, _p, _p],
     "dcq_pack_nunchaku": [_p, _i64, _i64, _i32, _p, _p],
     "dcq_gemm_f32": [_p, _i64, _i32, _p, _i64, _p, _i64, _i64, _i64, _i64, _f, _f, _p],
+    "dcq_gemm_f32_two_term": [_p, _i64, _i32, _p, _i64, _p, _i64, _i64, _i64, _i64, _f, _f, _p, _i64, _p],
     "dcq_cholesky_inverse_upper": [_p, _i64, _p, _f, _p, _p, _i64, _p, _p],
     "dcq_cholesky_inverse_upper_static": [_p, _i64, _p, _f, _p, _p, _p],
     "dcq_gemm_f64": [_p, _i32, _i64, _i32, _i64, _p, _i32, _i64, _i64, _p, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _p],

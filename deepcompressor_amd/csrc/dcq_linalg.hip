@@ -4,8 +4,10 @@
 // and used for the lazy weight update between sweep blocks (gptq.py:269).
 //
 // Small and medium products run on v_mfma_f32_32x32x2_f32, an exact float32 multiply-accumulate chain; large ones
-// run on the bf16 matrix pipe with every float32 operand split exactly into three bfloat16 terms (gemm_split_kernel:
-// six of the nine partial products, the rest is below one float32 rounding).  Both have float32 GEMM accuracy.
+// run on the 16-bit matrix pipe (gemm_split_kernel) with every float32 operand split into terms: two float16 terms
+// of the value scaled by a power of two per row / column (three of the four partial products), or, where that path's
+// magnitude pass cannot run, three bfloat16 terms (six of the nine partial products).  What is left out is of the
+// size of a float32 rounding: all three have float32 GEMM accuracy.
 //
 // How U is obtained.  With J the index reversal, factor J H J = R^T R (R upper).  Then H = V V^T with
 // V = J R^T J upper triangular, H^-1 = V^-T V^-1, and by uniqueness of the Cholesky factor U = V^-1 = J R^-T J:
@@ -52,6 +54,9 @@ struct GemmParams {
   int32_t k_above_m, k_below_m, k_below_n;
   int32_t tiles_m, tiles_n;
   int32_t vec_a, vec_b, vec_c;  // 16-byte accesses allowed (pointer and leading dimension aligned)
+  // two-term half-precision path only: bit patterns of max |A(m, :)| per row of C and max |B[:][n]| per column of C
+  const unsigned* a_absmax;
+  const unsigned* b_absmax;
 };
 
 // One 16-byte piece of a row: `FAST` pieces are whole and aligned; otherwise every element is guarded by `limit`
@@ -233,8 +238,12 @@ static int launch_gemm_variant(const GemmParams& p, hipStream_t s) {
 // 2^-23 |x x'|, the size of one float32 rounding, so the result has float32-GEMM accuracy while six bf16 matrix
 // instructions (16 x the rate of a float32 one each) stand where sixteen float32 ones did.
 //
+// With two float16 terms (11 significant bits each plus the sign of the second): x = h + l up to 2^-22 |x|, the
+// product is h h' + h l' + l h' on three matrix instructions, and the operands are first brought into float16's range,
+// exactly, by a power of two per row of A and per column of B that the epilogue takes out again (half_scale_of).
+//
 // Tile 128 x 128 per workgroup of 4 waves, K step 32.  Waves 0-1 stage the A operand, waves 2-3 the B operand:
-// float32 from global memory into registers (issued one K step ahead), split, written to LDS as three planes of
+// float32 from global memory into registers (issued one K step ahead), split, written to LDS as three (two) planes of
 // [k chunk of 8][row][8 bf16], the layout both operands of v_mfma_f32_16x16x32_bf16 read with one 16-byte access
 // per lane.  LDS row s of a tile holds the tile's row (or column) 64 (s / 64) + 4 (s % 16) + (s / 16) % 4 (stored at
 // row s ^ chunk, which spreads the 8-byte writes of a row-major A operand over the banks): a thread
@@ -244,12 +253,14 @@ static int launch_gemm_variant(const GemmParams& p, hipStream_t s) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kSplitK = 32;
 constexpr int kSplitChunkBytes = 128 * 16;                   // [row 128][8 bf16]
 constexpr int kSplitPlaneBytes = 4 * kSplitChunkBytes;       // 4 chunks of 8 = one K step
-constexpr int kSplitOperandBytes = 3 * kSplitPlaneBytes;
-constexpr int kSplitLdsBytes = 2 * kSplitOperandBytes;       // 48 KiB
+constexpr int split_operand_bytes(int planes) { return planes * kSplitPlaneBytes; }
+constexpr int split_lds_bytes(int planes) { return 2 * split_operand_bytes(planes); }  // 48 KiB (3 planes) / 32 KiB (2)
 
 __device__ __forceinline__ void split_pair(f32x2 v, unsigned& h, unsigned& m, unsigned& l) {
   h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
@@ -261,23 +272,53 @@ __device__ __forceinline__ void split_pair(f32x2 v, unsigned& h, unsigned& m, un
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
-// 8 consecutive-k values of one row -> the row's 16 bytes in each of the three planes
+// two float16 terms: h = round-to-nearest of v, l = round-to-nearest of what h left (v - h is exact in float32)
+__device__ __forceinline__ void split_pair(f32x2 v, unsigned& h, unsigned& l) {
+  const f16x2 hh = __builtin_convertvector(v, f16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  const f32x2 r = v - __builtin_convertvector(hh, f32x2);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
+// 8 consecutive-k values of one row -> the row's 16 bytes in each of the planes
+template <int PLANES>
 __device__ __forceinline__ void split_store(const float (&x)[8], unsigned char* at) {
-  uint4 h, m, l;
-  split_pair(f32x2{x[0], x[1]}, h.x, m.x, l.x);
-  split_pair(f32x2{x[2], x[3]}, h.y, m.y, l.y);
-  split_pair(f32x2{x[4], x[5]}, h.z, m.z, l.z);
-  split_pair(f32x2{x[6], x[7]}, h.w, m.w, l.w);
-  *reinterpret_cast<uint4*>(at) = h;
-  *reinterpret_cast<uint4*>(at + kSplitPlaneBytes) = m;
-  *reinterpret_cast<uint4*>(at + 2 * kSplitPlaneBytes) = l;
+  if constexpr (PLANES == 3) {
+    uint4 h, m, l;
+    split_pair(f32x2{x[0], x[1]}, h.x, m.x, l.x);
+    split_pair(f32x2{x[2], x[3]}, h.y, m.y, l.y);
+    split_pair(f32x2{x[4], x[5]}, h.z, m.z, l.z);
+    split_pair(f32x2{x[6], x[7]}, h.w, m.w, l.w);
+    *reinterpret_cast<uint4*>(at) = h;
+    *reinterpret_cast<uint4*>(at + kSplitPlaneBytes) = m;
+    *reinterpret_cast<uint4*>(at + 2 * kSplitPlaneBytes) = l;
+  } else {
+    uint4 h, l;
+    split_pair(f32x2{x[0], x[1]}, h.x, l.x);
+    split_pair(f32x2{x[2], x[3]}, h.y, l.y);
+    split_pair(f32x2{x[4], x[5]}, h.z, l.z);
+    split_pair(f32x2{x[6], x[7]}, h.w, l.w);
+    *reinterpret_cast<uint4*>(at) = h;
+    *reinterpret_cast<uint4*>(at + kSplitPlaneBytes) = l;
+  }
+}
+
+// The power of two that brings a row (or column) of largest magnitude `absmax_bits` (a float32 bit pattern) into
+// [2^14, 2^15), and its reciprocal.  Zero, denormal and non-finite maxima leave the values as they are.
+__device__ __forceinline__ void half_scale_of(unsigned absmax_bits, float& scale, float& inverse) {
+  const int ex = static_cast<int>((absmax_bits >> 23) & 0xffu);
+  int se = (ex == 0 || ex == 255) ? 127 : 268 - ex;
+  se = min(max(se, 1), 253);
+  scale = __builtin_bit_cast(float, static_cast<unsigned>(se) << 23);
+  inverse = __builtin_bit_cast(float, static_cast<unsigned>(254 - se) << 23);
 }
 
 __device__ __forceinline__ int split_row_of(int s) { return 64 * (s >> 6) + 4 * (s & 15) + ((s >> 4) & 3); }
 
-template <bool A_KMAJOR, bool FAST>
+template <bool A_KMAJOR, bool FAST, int PLANES>
 __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned char* lds, int m0, int n0, int k_begin,
                                                 int nk) {
+  constexpr int kOperandBytes = split_operand_bytes(PLANES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const bool stages_a = tid < 128;  // uniform per wave
@@ -285,6 +326,21 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
   // k-major operand: thread = (4 consecutive columns 4 q.., k chunk kc); row-major A: thread = piece u % 8 of 8 rows
   float4 regs[2][8];  // two sets of staging registers, used in turn: K step kt + 2 is requested while kt is multiplied
   const int q = u & 31, kc = u >> 5;
+  // two-term path: the scale of each row (row-major A) or column (k-major operand) this thread stages
+  float sc[8] = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
+  if constexpr (PLANES == 2) {
+    float unused;
+    if (stages_a && !A_KMAJOR) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it)
+        half_scale_of(p.a_absmax[min(m0 + split_row_of(16 * it + (u >> 3)), p.M - 1)], sc[it], unused);
+    } else {
+      const unsigned* absmax = stages_a ? p.a_absmax : p.b_absmax;
+      const int c0 = (stages_a ? m0 : n0) + 4 * q, limit = stages_a ? p.M : p.N;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) half_scale_of(absmax[min(c0 + e, limit - 1)], sc[e], unused);
+    }
+  }
   auto load_stage = [&](int kt, const int set) __attribute__((always_inline)) {
     const int k0 = k_begin + kt * kSplitK;
     if (stages_a && !A_KMAJOR) {
@@ -303,7 +359,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
     }
   };
   auto store_stage = [&](const int set) __attribute__((always_inline)) {
-    unsigned char* img = lds + (stages_a ? 0 : kSplitOperandBytes);
+    unsigned char* img = lds + (stages_a ? 0 : kOperandBytes);
     if (stages_a && !A_KMAJOR) {
       const int ck = (u & 7) >> 1;  // the piece's k chunk; its half of the chunk: u % 2
 #pragma unroll
@@ -311,32 +367,44 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
         const int srow = 16 * it + (u >> 3);
         const bool live = m0 + split_row_of(srow) < p.M;
         const float4 v = live ? regs[set][it] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        uint2 h, m, l;
-        split_pair(f32x2{v.x, v.y}, h.x, m.x, l.x);
-        split_pair(f32x2{v.z, v.w}, h.y, m.y, l.y);
         unsigned char* at = img + ck * kSplitChunkBytes + (srow ^ ck) * 16 + (u & 1) * 8;
-        *reinterpret_cast<uint2*>(at) = h;
-        *reinterpret_cast<uint2*>(at + kSplitPlaneBytes) = m;
-        *reinterpret_cast<uint2*>(at + 2 * kSplitPlaneBytes) = l;
+        if constexpr (PLANES == 3) {
+          uint2 h, m, l;
+          split_pair(f32x2{v.x, v.y}, h.x, m.x, l.x);
+          split_pair(f32x2{v.z, v.w}, h.y, m.y, l.y);
+          *reinterpret_cast<uint2*>(at) = h;
+          *reinterpret_cast<uint2*>(at + kSplitPlaneBytes) = m;
+          *reinterpret_cast<uint2*>(at + 2 * kSplitPlaneBytes) = l;
+        } else {
+          uint2 h, l;
+          split_pair(f32x2{v.x * sc[it], v.y * sc[it]}, h.x, l.x);
+          split_pair(f32x2{v.z * sc[it], v.w * sc[it]}, h.y, l.y);
+          *reinterpret_cast<uint2*>(at) = h;
+          *reinterpret_cast<uint2*>(at + kSplitPlaneBytes) = l;
+        }
       }
     } else {
       // rows (q % 16) + 16 c + 64 (q / 16), c = 0..3; kc only flips the two lowest bits of the row
       unsigned char* at = img + kc * kSplitChunkBytes + (((q & 15) ^ kc) + 64 * (q >> 4)) * 16;
       {
-        const float x[8] = {regs[set][0].x, regs[set][1].x, regs[set][2].x, regs[set][3].x, regs[set][4].x, regs[set][5].x, regs[set][6].x, regs[set][7].x};
-        split_store(x, at);
+        const float x[8] = {regs[set][0].x * sc[0], regs[set][1].x * sc[0], regs[set][2].x * sc[0], regs[set][3].x * sc[0],
+                            regs[set][4].x * sc[0], regs[set][5].x * sc[0], regs[set][6].x * sc[0], regs[set][7].x * sc[0]};
+        split_store<PLANES>(x, at);
       }
       {
-        const float x[8] = {regs[set][0].y, regs[set][1].y, regs[set][2].y, regs[set][3].y, regs[set][4].y, regs[set][5].y, regs[set][6].y, regs[set][7].y};
-        split_store(x, at + 16 * 16);
+        const float x[8] = {regs[set][0].y * sc[1], regs[set][1].y * sc[1], regs[set][2].y * sc[1], regs[set][3].y * sc[1],
+                            regs[set][4].y * sc[1], regs[set][5].y * sc[1], regs[set][6].y * sc[1], regs[set][7].y * sc[1]};
+        split_store<PLANES>(x, at + 16 * 16);
       }
       {
-        const float x[8] = {regs[set][0].z, regs[set][1].z, regs[set][2].z, regs[set][3].z, regs[set][4].z, regs[set][5].z, regs[set][6].z, regs[set][7].z};
-        split_store(x, at + 32 * 16);
+        const float x[8] = {regs[set][0].z * sc[2], regs[set][1].z * sc[2], regs[set][2].z * sc[2], regs[set][3].z * sc[2],
+                            regs[set][4].z * sc[2], regs[set][5].z * sc[2], regs[set][6].z * sc[2], regs[set][7].z * sc[2]};
+        split_store<PLANES>(x, at + 32 * 16);
       }
       {
-        const float x[8] = {regs[set][0].w, regs[set][1].w, regs[set][2].w, regs[set][3].w, regs[set][4].w, regs[set][5].w, regs[set][6].w, regs[set][7].w};
-        split_store(x, at + 48 * 16);
+        const float x[8] = {regs[set][0].w * sc[3], regs[set][1].w * sc[3], regs[set][2].w * sc[3], regs[set][3].w * sc[3],
+                            regs[set][4].w * sc[3], regs[set][5].w * sc[3], regs[set][6].w * sc[3], regs[set][7].w * sc[3]};
+        split_store<PLANES>(x, at + 48 * 16);
       }
     }
   };
@@ -355,25 +423,38 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
   __syncthreads();
   const int g = lane >> 4, j = lane & 15;
   const unsigned char* fa = lds + g * kSplitChunkBytes + (64 * wr + (j ^ g)) * 16;
-  const unsigned char* fb = lds + kSplitOperandBytes + g * kSplitChunkBytes + (64 * wc + (j ^ g)) * 16;
+  const unsigned char* fb = lds + kOperandBytes + g * kSplitChunkBytes + (64 * wc + (j ^ g)) * 16;
   auto multiply_step = [&]() __attribute__((always_inline)) {
-    bf16x8 a[3][4], b[3][4];
+    uint4 a[PLANES][4], b[PLANES][4];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        a[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fa + pl * kSplitPlaneBytes + i * 256));
-        b[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fb + pl * kSplitPlaneBytes + i * 256));
+        a[pl][i] = *reinterpret_cast<const uint4*>(fa + pl * kSplitPlaneBytes + i * 256);
+        b[pl][i] = *reinterpret_cast<const uint4*>(fb + pl * kSplitPlaneBytes + i * 256);
       }
     // smallest terms first
-    constexpr int pa[6] = {0, 2, 1, 0, 1, 0}, pb[6] = {2, 0, 1, 1, 0, 0};
+    if constexpr (PLANES == 3) {
+      constexpr int pa[6] = {0, 2, 1, 0, 1, 0}, pb[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < 6; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa[t]][i], b[pb[t]][n], acc[i][n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pa[t]][i]),
+                                                                __builtin_bit_cast(bf16x8, b[pb[t]][n]), acc[i][n], 0, 0, 0);
+    } else {
+      constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[pa[t]][i]),
+                                                               __builtin_bit_cast(f16x8, b[pb[t]][n]), acc[i][n], 0, 0, 0);
+    }
   };
   // one K step: multiply the image of step kt, then replace it by step kt + 1 (register set `have`); set `next` takes kt + 2
   auto step = [&](int kt, const int have, const int next) __attribute__((always_inline)) {
@@ -389,12 +470,27 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
   }
   // lane (g, j) of block (i, n) holds C[64 wr + 16 g + 4 r + i][64 wc + 4 j + n], r = 0..3
   const bool whole = m0 + 128 <= p.M && n0 + 128 <= p.N && p.vec_c;  // uniform
+  float back_b[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // two-term path: the scales are taken out again, exactly
+  if constexpr (PLANES == 2) {
+    float unused;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) half_scale_of(p.b_absmax[min(n0 + 64 * wc + 4 * j + e, p.N - 1)], unused, back_b[e]);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + 64 * wr + 16 * g + 4 * r + i, col = n0 + 64 * wc + 4 * j;
-      float v[4] = {p.alpha * acc[i][0][r], p.alpha * acc[i][1][r], p.alpha * acc[i][2][r], p.alpha * acc[i][3][r]};
+      float v[4];
+      if constexpr (PLANES == 2) {
+        float unused, back_a;
+        half_scale_of(p.a_absmax[min(row, p.M - 1)], unused, back_a);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = p.alpha * ((acc[i][e][r] * back_a) * back_b[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = p.alpha * acc[i][e][r];
+      }
       float* c = p.C + static_cast<int64_t>(row) * p.ldc + col;
       if (whole) {
         float4 out = make_float4(v[0], v[1], v[2], v[3]);
@@ -411,7 +507,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
     }
 }
 
-template <bool A_KMAJOR>
+template <bool A_KMAJOR, int PLANES>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(const GemmParams p) {
   extern __shared__ __align__(16) unsigned char gemm_smem[];
   int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
@@ -426,23 +522,107 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(const GemmP
   const int nk = k_end > k_begin ? (k_end - k_begin) / kSplitK : 0;
   const bool fast = p.vec_a && p.vec_b && n0 + 128 <= p.N && (!A_KMAJOR || m0 + 128 <= p.M);
   if (fast) {
-    gemm_split_tile<A_KMAJOR, true>(p, gemm_smem, m0, n0, k_begin, nk);
+    gemm_split_tile<A_KMAJOR, true, PLANES>(p, gemm_smem, m0, n0, k_begin, nk);
   } else {
-    gemm_split_tile<A_KMAJOR, false>(p, gemm_smem, m0, n0, k_begin, nk);
+    gemm_split_tile<A_KMAJOR, false, PLANES>(p, gemm_smem, m0, n0, k_begin, nk);
   }
 }
 
-template <bool A_KMAJOR>
+template <bool A_KMAJOR, int PLANES>
 static int launch_gemm_split(const GemmParams& p, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(p.tiles_m) * static_cast<unsigned>(p.tiles_n);
-  hipLaunchKernelGGL(gemm_split_kernel<A_KMAJOR>, dim3(grid), dim3(kGemmThreads), kSplitLdsBytes, s, p);
+  hipLaunchKernelGGL((gemm_split_kernel<A_KMAJOR, PLANES>), dim3(grid), dim3(kGemmThreads), split_lds_bytes(PLANES), s, p);
   DCQ_LAUNCH_CHECK("gemm_split_kernel launch");
+  return DCQ_OK;
+}
+
+// Largest magnitudes for the two-term path, as float32 bit patterns (which order like the magnitudes; a NaN sorts
+// above everything).  `diag` restricts a triangular operand to the kNb-blocks that can be non-zero: what lies in the
+// blocks beyond may never have been written.
+//   columns: out[c] = max(out[c], max_r |src[r][c]|), r < rows (diag: r < end of the block of c); out starts zeroed
+__global__ __launch_bounds__(256) void col_absmax_kernel(const float* __restrict__ src, int64_t ld, int rows, int cols,
+                                                         int diag, unsigned* __restrict__ out) {
+  __shared__ uint4 part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const int r0 = blockIdx.y * 64 + wave * 16;
+  uint4 m = make_uint4(0u, 0u, 0u, 0u);
+  if (c < cols) {
+    int r_end = min(r0 + 16, rows);
+    if (diag) r_end = min(r_end, (c / kNb + 1) * kNb);
+    for (int r = r0; r < r_end; ++r) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src + static_cast<int64_t>(r) * ld + c);
+      m.x = max(m.x, v.x & 0x7fffffffu);
+      m.y = max(m.y, v.y & 0x7fffffffu);
+      m.z = max(m.z, v.z & 0x7fffffffu);
+      m.w = max(m.w, v.w & 0x7fffffffu);
+    }
+  }
+  part[wave][lane] = m;
+  __syncthreads();
+  if (wave == 0 && c < cols) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const uint4 o = part[w][lane];
+      m.x = max(m.x, o.x);
+      m.y = max(m.y, o.y);
+      m.z = max(m.z, o.z);
+      m.w = max(m.w, o.w);
+    }
+    if (m.x) atomicMax(out + c, m.x);
+    if (m.y) atomicMax(out + c + 1, m.y);
+    if (m.z) atomicMax(out + c + 2, m.z);
+    if (m.w) atomicMax(out + c + 3, m.w);
+  }
+}
+
+//   rows: out[r] = max_c |src[r][c]|, c < cols (diag > 0: c from the start of the block of r; diag < 0: c up to the
+//   end of the block of r); one wave per row
+__global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict__ src, int64_t ld, int rows, int cols,
+                                                         int diag, unsigned* __restrict__ out) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c_begin = diag > 0 ? row / kNb * kNb : 0;
+  const int c_end = diag < 0 ? min(cols, (row / kNb + 1) * kNb) : cols;
+  unsigned m = 0u;
+  for (int c = c_begin + 4 * lane; c < c_end; c += 256) {
+    const uint4 v = *reinterpret_cast<const uint4*>(src + static_cast<int64_t>(row) * ld + c);
+    m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, static_cast<unsigned>(__shfl_xor(static_cast<int>(m), o)));
+  if (lane == 0) out[row] = m;
+}
+
+// Fills absmax[0 .. M) for A and absmax[M .. M + N) for B (one vector when both operands are the same k-major matrix).
+static int launch_absmax(GemmParams& p, bool a_kmajor, unsigned* absmax, hipStream_t s) {
+  const bool same = a_kmajor && p.A == p.B && p.lda == p.ldb && p.M == p.N && !p.k_below_m && !p.k_below_n;
+  unsigned* for_a = absmax;
+  unsigned* for_b = same ? absmax : absmax + p.M;
+  int rc = hip_check(hipMemsetAsync(absmax, 0, static_cast<size_t>(same ? p.N : p.M + p.N) * 4, s), "hipMemsetAsync(absmax)");
+  if (rc != DCQ_OK) return rc;
+  const dim3 grid_b(static_cast<unsigned>((p.N + 255) / 256), static_cast<unsigned>((p.K + 63) / 64));
+  hipLaunchKernelGGL(col_absmax_kernel, grid_b, dim3(256), 0, s, p.B, p.ldb, p.K, p.N, p.k_below_n, for_b);
+  DCQ_LAUNCH_CHECK("col_absmax_kernel launch");
+  if (a_kmajor && !same) {
+    const dim3 grid_a(static_cast<unsigned>((p.M + 255) / 256), static_cast<unsigned>((p.K + 63) / 64));
+    hipLaunchKernelGGL(col_absmax_kernel, grid_a, dim3(256), 0, s, p.A, p.lda, p.K, p.M, p.k_below_m, for_a);
+    DCQ_LAUNCH_CHECK("col_absmax_kernel launch");
+  } else if (!a_kmajor) {
+    hipLaunchKernelGGL(row_absmax_kernel, dim3(static_cast<unsigned>((p.M + 3) / 4)), dim3(256), 0, s, p.A, p.lda, p.M,
+                       p.K, p.k_above_m ? 1 : (p.k_below_m ? -1 : 0), for_a);
+    DCQ_LAUNCH_CHECK("row_absmax_kernel launch");
+  }
+  p.a_absmax = for_a;
+  p.b_absmax = for_b;
   return DCQ_OK;
 }
 
 // `path`: kGemmAuto picks by problem size (results of the two float32 tile sizes are bit-identical; the split path
 // rounds differently), kGemmFloat32 / kGemmSplit force one -- for callers whose results must not depend on M.
-static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s, int path = kGemmAuto) {
+// `absmax`: scratch of M + N words; when given, a product that takes the split path runs on two float16 terms per
+// operand (half the matrix instructions) instead of three bfloat16 terms.
+static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s, int path = kGemmAuto, unsigned* absmax = nullptr) {
   GemmParams p = pin;
   if (p.M <= 0 || p.N <= 0) return DCQ_OK;
   p.vec_a = (reinterpret_cast<uintptr_t>(p.A) & 15u) == 0 && p.lda % 4 == 0;
@@ -456,7 +636,14 @@ static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s, int 
   const int T = split || big_tiles >= 512 ? 128 : 64;
   p.tiles_m = (p.M + T - 1) / T;
   p.tiles_n = (p.N + T - 1) / T;
-  if (split) return a_kmajor ? launch_gemm_split<true>(p, s) : launch_gemm_split<false>(p, s);
+  // (the two-term path reads whole aligned pieces in its magnitude pass, and a k-major A clipped from below has no
+  // such pass)
+  if (split && absmax != nullptr && p.vec_a && p.vec_b && p.N % 4 == 0 && !(a_kmajor && (p.M % 4 != 0 || p.k_above_m))) {
+    const int rc = launch_absmax(p, a_kmajor, absmax, s);
+    if (rc != DCQ_OK) return rc;
+    return a_kmajor ? launch_gemm_split<true, 2>(p, s) : launch_gemm_split<false, 2>(p, s);
+  }
+  if (split) return a_kmajor ? launch_gemm_split<true, 3>(p, s) : launch_gemm_split<false, 3>(p, s);
   if (T == 64) return a_kmajor ? launch_gemm_variant<true, 64>(p, s) : launch_gemm_variant<false, 64>(p, s);
   return a_kmajor ? launch_gemm_variant<true, 128>(p, s) : launch_gemm_variant<false, 128>(p, s);
 }
@@ -819,6 +1006,7 @@ struct CholPlan {
   int64_t np;
   int nblk;
   size_t a_bytes, x_bytes, t_bytes;
+  size_t m_bytes;  // row / column magnitudes of the operands of one large product
 };
 
 static CholPlan plan_chol(int64_t n) {
@@ -829,6 +1017,7 @@ static CholPlan plan_chol(int64_t n) {
   c.x_bytes = c.a_bytes;
   const int64_t half = (c.nblk + 1) / 2 * kNb;
   c.t_bytes = static_cast<size_t>(half) * half * 4;
+  c.m_bytes = static_cast<size_t>(c.np) * 4;  // M + N of any product of the recursion is at most np
   return c;
 }
 
@@ -839,7 +1028,8 @@ static CholPlan plan_chol(int64_t n) {
 //     A22 -= R12^T R12                (upper triangle only; K = size of the first half, so C is touched once)
 //     [R22, X22] = recurse(A22)
 //     X12 = -X11 (R12 X22)
-static int factor_invert(float* A, float* X, float* T, int64_t np, int lo, int hi, int32_t* info, hipStream_t s) {
+static int factor_invert(float* A, float* X, float* T, unsigned* mags, int64_t np, int lo, int hi, int32_t* info,
+                         hipStream_t s) {
   if (hi - lo == 1) {
     const int64_t off = (static_cast<int64_t>(lo) * kNb) * (np + 1);
     hipLaunchKernelGGL(panel_factor_kernel, dim3(1), dim3(kPanelThreads), 0, s, A + off, np, X + off, np, info, lo * kNb);
@@ -866,7 +1056,7 @@ static int factor_invert(float* A, float* X, float* T, int64_t np, int lo, int h
   const int m1 = (mid - lo) * kNb, m2 = (hi - mid) * kNb;
   const int64_t o1 = static_cast<int64_t>(lo) * kNb, o2 = static_cast<int64_t>(mid) * kNb;
   float* a12 = A + o1 * np + o2;
-  int rc = factor_invert(A, X, T, np, lo, mid, info, s);
+  int rc = factor_invert(A, X, T, mags, np, lo, mid, info, s);
   if (rc != DCQ_OK) return rc;
   {  // R12 = X11^T A12 -> T, then copied back (a GEMM cannot overwrite an operand other blocks still read)
     GemmParams g{};
@@ -882,7 +1072,7 @@ static int factor_invert(float* A, float* X, float* T, int64_t np, int lo, int h
     g.alpha = 1.0f;
     g.beta = 0.0f;
     g.k_below_m = 1;
-    rc = launch_gemm(g, true, s);
+    rc = launch_gemm(g, true, s, kGemmAuto, mags);
     if (rc != DCQ_OK) return rc;
     rc = hip_check(hipMemcpy2DAsync(a12, np * 4, T, static_cast<size_t>(m2) * 4, static_cast<size_t>(m2) * 4, m1,
                                     hipMemcpyDeviceToDevice, s),
@@ -903,10 +1093,10 @@ static int factor_invert(float* A, float* X, float* T, int64_t np, int lo, int h
     g.alpha = -1.0f;
     g.beta = 1.0f;
     g.upper_only = 1;
-    rc = launch_gemm(g, true, s);
+    rc = launch_gemm(g, true, s, kGemmAuto, mags);
     if (rc != DCQ_OK) return rc;
   }
-  rc = factor_invert(A, X, T, np, mid, hi, info, s);
+  rc = factor_invert(A, X, T, mags, np, mid, hi, info, s);
   if (rc != DCQ_OK) return rc;
   {  // T = R12 X22 (X22 upper: k <= n)
     GemmParams g{};
@@ -922,7 +1112,7 @@ static int factor_invert(float* A, float* X, float* T, int64_t np, int lo, int h
     g.alpha = 1.0f;
     g.beta = 0.0f;
     g.k_below_n = 1;
-    rc = launch_gemm(g, false, s);
+    rc = launch_gemm(g, false, s, kGemmAuto, mags);
     if (rc != DCQ_OK) return rc;
   }
   {  // X12 = -X11 T (X11 upper: k >= m)
@@ -939,7 +1129,7 @@ static int factor_invert(float* A, float* X, float* T, int64_t np, int lo, int h
     g.alpha = -1.0f;
     g.beta = 0.0f;
     g.k_above_m = 1;
-    rc = launch_gemm(g, false, s);
+    rc = launch_gemm(g, false, s, kGemmAuto, mags);
     if (rc != DCQ_OK) return rc;
   }
   return DCQ_OK;
@@ -956,7 +1146,8 @@ int cholesky_inverse_upper_on(const float* H, int64_t n, const int64_t* perm, fl
 // pointer is ever handed to kernels and memsets.
 // ---------------------------------------------------------------------------------------------
 constexpr int kStaticCholMaxN = 2048;
-constexpr size_t kStaticCholBytes = 2ull * kStaticCholMaxN * kStaticCholMaxN * 4 + 1ull * (kStaticCholMaxN / 2) * (kStaticCholMaxN / 2) * 4;
+constexpr size_t kStaticCholBytes = 2ull * kStaticCholMaxN * kStaticCholMaxN * 4 +
+                                    1ull * (kStaticCholMaxN / 2) * (kStaticCholMaxN / 2) * 4 + kStaticCholMaxN * 4;
 static __device__ __align__(256) unsigned char scratch[kStaticCholBytes];  // 36 MiB per GPU, for the process's lifetime
 
 constexpr int kMaxDevices = 64;
@@ -988,7 +1179,8 @@ using namespace dcq;
 namespace dcq {
 
 int gemm_f32_on_path(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
-                     int64_t M, int64_t N, int64_t K, float alpha, float beta, hipStream_t stream, int path) {
+                     int64_t M, int64_t N, int64_t K, float alpha, float beta, hipStream_t stream, int path,
+                     unsigned* magnitudes) {
   DCQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, DCQ_ERR_ARGUMENT, "negative size");
   if (M == 0 || N == 0) return DCQ_OK;
   DCQ_REQUIRE(A && B && C, DCQ_ERR_ARGUMENT, "NULL buffer");
@@ -1006,7 +1198,7 @@ int gemm_f32_on_path(const float* A, int64_t lda, int32_t a_kmajor, const float*
   g.K = static_cast<int32_t>(K);
   g.alpha = alpha;
   g.beta = beta;
-  return launch_gemm(g, a_kmajor != 0, stream, path);
+  return launch_gemm(g, a_kmajor != 0, stream, path, magnitudes);
 }
 
 }  // namespace dcq
@@ -1015,13 +1207,42 @@ extern "C" {
 
 int dcq_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
                  int64_t M, int64_t N, int64_t K, float alpha, float beta, dcq_stream_t stream) {
-  return gemm_f32_on_path(A, lda, a_kmajor, B, ldb, C, ldc, M, N, K, alpha, beta, static_cast<hipStream_t>(stream), kGemmAuto);
+  return gemm_f32_on_path(A, lda, a_kmajor, B, ldb, C, ldc, M, N, K, alpha, beta, static_cast<hipStream_t>(stream), kGemmAuto, nullptr);
+}
+
+int dcq_gemm_f32_two_term(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
+                          int64_t M, int64_t N, int64_t K, float alpha, float beta, void* workspace, int64_t workspace_bytes,
+                          dcq_stream_t stream) {
+  DCQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, DCQ_ERR_ARGUMENT, "negative size");
+  if (M == 0 || N == 0) return DCQ_OK;
+  DCQ_REQUIRE(A && B && C && workspace, DCQ_ERR_ARGUMENT, "NULL buffer");
+  DCQ_REQUIRE(K % 32 == 0 && N % 4 == 0 && (!a_kmajor || M % 4 == 0), DCQ_ERR_UNSUPPORTED,
+              "K must be a multiple of 32, N (and M of a k-major A) of 4 (got M %lld N %lld K %lld)", (long long)M,
+              (long long)N, (long long)K);
+  DCQ_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), DCQ_ERR_UNSUPPORTED, "size too large");
+  DCQ_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(B) & 15u) == 0 && lda % 4 == 0 &&
+                  ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(workspace) & 3u) == 0,
+              DCQ_ERR_UNSUPPORTED, "A and B must be 16-byte aligned with leading dimensions that are multiples of 4");
+  DCQ_REQUIRE(workspace_bytes >= (M + N) * 4, DCQ_ERR_ARGUMENT, "workspace too small: (M + N) * 4 bytes are needed");
+  GemmParams g{};
+  g.A = A;
+  g.lda = lda;
+  g.B = B;
+  g.ldb = ldb;
+  g.C = C;
+  g.ldc = ldc;
+  g.M = static_cast<int32_t>(M);
+  g.N = static_cast<int32_t>(N);
+  g.K = static_cast<int32_t>(K);
+  g.alpha = alpha;
+  g.beta = beta;
+  return launch_gemm(g, a_kmajor != 0, static_cast<hipStream_t>(stream), kGemmSplit, static_cast<unsigned*>(workspace));
 }
 
 int64_t dcq_cholesky_workspace_bytes(int64_t n) {
   if (n <= 0) return 0;
   const CholPlan c = plan_chol(n);
-  return static_cast<int64_t>(c.a_bytes + c.x_bytes + c.t_bytes);
+  return static_cast<int64_t>(c.a_bytes + c.x_bytes + c.t_bytes + c.m_bytes);
 }
 
 int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U, void* workspace,
@@ -1058,6 +1279,7 @@ int cholesky_inverse_upper_on(const float* H, int64_t n, const int64_t* perm, fl
   float* A = reinterpret_cast<float*>(ws);
   float* X = reinterpret_cast<float*>(ws + c.a_bytes);
   float* T = reinterpret_cast<float*>(ws + c.a_bytes + c.x_bytes);
+  unsigned* mags = reinterpret_cast<unsigned*>(ws + c.a_bytes + c.x_bytes + c.t_bytes);
   const int64_t np = c.np;
   int rc = hip_check(hipMemsetAsync(info, 0x7f, 4, s), "hipMemsetAsync(info)");  // 0x7f7f7f7f = "no failure yet"
   if (rc != DCQ_OK) return rc;
@@ -1080,7 +1302,7 @@ int cholesky_inverse_upper_on(const float* H, int64_t n, const int64_t* perm, fl
   // halves of the diagonal blocks must read as zero.  Nothing ever reads a block strictly below the diagonal.
   hipLaunchKernelGGL(zero_diagonal_blocks_kernel, dim3(static_cast<unsigned>(c.nblk)), dim3(256), 0, s, X, np);
   DCQ_LAUNCH_CHECK("zero_diagonal_blocks_kernel launch");
-  rc = factor_invert(A, X, T, np, 0, c.nblk, info, s);
+  rc = factor_invert(A, X, T, mags, np, 0, c.nblk, info, s);
   if (rc != DCQ_OK) return rc;
   hipLaunchKernelGGL(flip_transpose_kernel, dim3(static_cast<unsigned>((n + 31) / 32), static_cast<unsigned>((n + 31) / 32)),
                      dim3(256), 0, s, X, np, U, n);

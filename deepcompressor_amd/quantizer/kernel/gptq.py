@@ -287,9 +287,11 @@ def hessian_accumulate(hessian: torch.Tensor, x: torch.Tensor, alpha: float, *, 
 
 
 def gemm_f32(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0,
-             a_transposed: bool = False) -> None:
+             a_transposed: bool = False, two_term: bool = False) -> None:
     """c = beta * c + alpha * a @ b on the float32 matrix-core path (``a`` holds a^T when ``a_transposed``).
-    Operands are 2-D float32 views with unit stride along their last dimension."""
+    Operands are 2-D float32 views with unit stride along their last dimension.  ``two_term`` forces the path that
+    multiplies two float16 terms per operand, scaled per row of ``a`` and per column of ``b``
+    (``dcq_gemm_f32_two_term``), which the inverse factor's large products take."""
     for t in (a, b, c):
         assert t.dtype == torch.float32 and t.ndim == 2 and t.stride(1) == 1, "float32 row-major views expected"
     K, N = b.shape
@@ -299,6 +301,12 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, alpha: float 
         return
     raw = lambda t: C.c_void_p(t.data_ptr())  # strided views: the leading dimensions carry the layout
     engine._require_gpu(c)
+    if two_term:
+        ws = _workspace(c.device, (M + N) * 4)
+        check(lib().dcq_gemm_f32_two_term(raw(a), a.stride(0), int(a_transposed), raw(b), b.stride(0), raw(c), c.stride(0),
+                                          M, N, K, float(alpha), float(beta), ptr(ws), ws.numel(), stream_of(c.device)),
+              "dcq_gemm_f32_two_term")
+        return
     check(lib().dcq_gemm_f32(raw(a), a.stride(0), int(a_transposed), raw(b), b.stride(0), raw(c), c.stride(0), M, N, K,
                              float(alpha), float(beta), stream_of(c.device)), "dcq_gemm_f32")
 
@@ -422,6 +430,7 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     # writes the far part of W LAZY_BLOCKS times less often.
     group_cols = SWEEP_COLUMNS * LAZY_BLOCKS
     err = torch.empty((R, group_cols), device=dev, dtype=torch.float32)
+    magnitudes = torch.empty(R + Cn, device=dev, dtype=torch.int32)  # scratch of the far updates' two-term products
     # The factorisation is enqueued, not waited for: the sweep goes into the stream right behind it, and only then is
     # the factorisation's flag read.  A failed attempt (a non-positive pivot: rare, U is garbage then and so is this
     # sweep's output) is repeated with more damping, as the reference does (gptq.py:209-233).
@@ -431,7 +440,8 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
         Wp = engine.gather_columns(W, perm, zero_columns=dead)  # dead channels zeroed, act-order (gptq.py:199-208)
         Q = torch.empty_like(Wp)  # the sweep writes every row and column
         check(lib().dcq_gptq_sweep(C.byref(step), ptr(Wp), Cn, R, Cn, ptr(U), ptr(s2), ptr(z2), z_scalar, rg_size,
-                                   cg_size, n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, stream_of(dev)),
+                                   cg_size, n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, ptr(magnitudes), magnitudes.numel() * 4,
+                                   stream_of(dev)),
               "dcq_gptq_sweep")
         if info is None:
             break

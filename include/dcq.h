@@ -293,6 +293,9 @@ int dcq_selftest_division(const float* x, const float* s, float* fast, float* re
  * side in Err[R][128 * lazy_blocks]; columns inside such a group are updated after every block, the columns
  * right of it once per group with one product of depth 128 * lazy_blocks (the same sums as the reference's
  * per-block update; only the float32 summation order differs).  U is [C][C] with leading dimension C.
+ * `workspace`: NULL, or (R + C) * 4 bytes (4-byte aligned) of scratch, with which the far updates of 2048 or more
+ * columns run as dcq_gemm_f32_two_term products (half the matrix instructions of the three-term path they take
+ * otherwise, float32-GEMM accuracy either way; a row's result depends on the choice but never on R).
  * ------------------------------------------------------------------------------------------- */
 int64_t dcq_hessian_workspace_bytes(int64_t T, int64_t C);
 
@@ -335,7 +338,7 @@ int dcq_gather_columns(const void* src, int32_t storage, int64_t ld_src, int64_t
 int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64_t C, const float* U,
                    const float* scale, const float* zero, float zero_scalar, int32_t row_group_size,
                    int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
-                   int32_t lazy_blocks, dcq_stream_t stream);
+                   int32_t lazy_blocks, void* workspace, int64_t workspace_bytes, dcq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense float32 linear algebra of GPTQ on the matrix cores.
@@ -348,6 +351,20 @@ int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64
  * 128 or more 128 x 128 tiles are computed on the bf16 matrix pipe from exact three-term bfloat16 splits of the
  * operands, so their low bits differ from those of a float32 multiply-accumulate chain.
  *
+ * dcq_gemm_f32_two_term: the same product from two float16 terms per operand, for any size.  Each row of A and each
+ * column of B is first scaled by the power of two that brings its largest magnitude into [2^14, 2^15) (the scales
+ * are taken out of the result again, exactly), then every value is split into h = float16(v) and l = float16(v - h)
+ * and the product accumulates h h' + h l' + l h' in float32: three float16 matrix instructions where the three-term
+ * path needs six.  A term pair misses at most 2^-22 of its value or 2^-39 of the largest magnitude in its row or
+ * column, whichever is larger, and the term left out is of that size too, so the error per element stays within
+ * 3 * 2^-22 of sum |a||b| however short K is (measured: 4.7e-7 at K = 32; 1.4e-7 ... 2e-7 from K = 512 on, where a
+ * float32 multiply-accumulate chain has 2.5e-7 ... 3.6e-7, also with rows and columns graded over twelve decades).  A row or column whose
+ * largest magnitude is zero, denormal or not finite is left unscaled (non-finite values give non-finite results).
+ * Requires 16-byte aligned A and B, lda and ldb multiples of 4, K a multiple of 32, N (and M when a_kmajor) a multiple
+ * of 4 (DCQ_ERR_UNSUPPORTED otherwise); `workspace`: (M + N) * 4 bytes, 4-byte aligned, for the magnitudes.  No
+ * reference counterpart beyond the float32 matmul it stands for; dcq_cholesky_inverse_upper's products of 128 or more
+ * tiles and dcq_gptq_sweep's far updates run on it.
+ *
  * dcq_cholesky_inverse_upper: U[n][n] (upper triangular, row-major) with U^T U = S^-1 where
  *     S = P H' P^T + diag_add * I,   H' = H with zero diagonal entries set to 1 (gptq.py:199-201),
  *     P = row/column gather by perm[n] (act-order, gptq.py:204-208; NULL = identity).
@@ -359,6 +376,10 @@ int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64
  * ------------------------------------------------------------------------------------------- */
 int dcq_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
                  int64_t M, int64_t N, int64_t K, float alpha, float beta, dcq_stream_t stream);
+
+int dcq_gemm_f32_two_term(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
+                          int64_t M, int64_t N, int64_t K, float alpha, float beta, void* workspace, int64_t workspace_bytes,
+                          dcq_stream_t stream);
 
 int64_t dcq_cholesky_workspace_bytes(int64_t n);
 

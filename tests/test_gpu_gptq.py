@@ -97,6 +97,75 @@ def test_gemm_f32_matches_float64(M, N, K, a_t):
     assert err < 2e-5 * (K ** 0.5), err
 
 
+@pytest.mark.parametrize("M,N,K,a_t", [(128, 128, 32, False), (96, 200, 128, False), (300, 516, 64, True),
+                                       (1024, 2048, 128, False), (260, 132, 256, True), (4, 4, 32, False),
+                                       (131, 76, 64, False), (2952, 3076, 32, True), (3001, 2900, 160, False),
+                                       (2904, 3000, 96, True)])
+def test_gemm_f32_two_term_matches_float64(M, N, K, a_t):
+    """The two-float16-term path (per-row / per-column power-of-two scales, h h' + h l' + l h'): ragged edges, both A
+    layouts, strided views, operands graded over twelve decades along M and N and four along K.  Bar: the error of
+    every element within 8e-7 of sum |a||b| -- each operand's term pair carries a relative error of up to 2^-22 and the
+    term left out another, 3 x 2.4e-7 at worst when K is too short to average them (observed: 4.7e-7 at K = 32, 2e-7 at
+    K >= 512; a float32 multiply-accumulate chain in torch reaches 2.5e-7 ... 3.6e-7 on the long shapes)."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    grade = lambda n: torch.logspace(-6, 6, n)[torch.randperm(n, generator=g)]
+    a = torch.randn(M, K, generator=g) * grade(M)[:, None] * torch.logspace(-2, 2, K)[None, :]
+    b_full = torch.randn(K, N + 12, generator=g)
+    b_full[:, 12:] *= grade(N)[None, :]
+    c_full = torch.randn(M, N + 8, generator=g)
+    b, c = b_full[:, 12:12 + N], c_full[:, 8:]
+    want = 0.5 * c.double() - 1.25 * (a.double() @ b.double())
+    bound = 0.5 * c.double().abs() + 1.25 * (a.double().abs() @ b.double().abs())
+    a_dev = a.T.contiguous().cuda() if a_t else a.cuda()
+    b_dev, c_dev = b_full.cuda(), c_full.cuda()
+    gemm_f32(a_dev, b_dev[:, 12:12 + N], c_dev[:, 8:], alpha=-1.25, beta=0.5, a_transposed=a_t, two_term=True)
+    got = c_dev.cpu()
+    assert torch.equal(got[:, :8], c_full[:, :8]), "columns outside the view must stay untouched"
+    err = ((got[:, 8:].double() - want).abs() / bound).max().item()
+    assert err < 8e-7, err
+
+
+def test_gemm_f32_two_term_special_rows_and_refusals():
+    """Rows / columns of zeros stay exact zeros, a non-finite value reaches exactly the results it belongs to, the
+    smallest and largest float32 magnitudes survive the scaling; shapes and alignments the path does not take are
+    refused, not computed some other way."""
+    import ctypes as C
+
+    from deepcompressor_amd import _lib
+
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(64, 96, generator=g), torch.randn(96, 128, generator=g)
+    a[3] = 0
+    b[:, 5] = 0
+    a[7] *= 1e-36
+    b[:, 9] *= 1e36
+    a[11, 2] = float("inf")
+    b[4, 13] = float("nan")
+    out = torch.full((64, 128), 7.0, device="cuda")
+    gemm_f32(a.cuda(), b.cuda(), out, two_term=True)
+    got, want = out.cpu(), a.double() @ b.double()
+    assert (got[3] == 0)[torch.arange(128) != 13].all() and (got[:, 5] == 0)[torch.arange(64) != 11].all()
+    bad = torch.zeros(64, 128, dtype=torch.bool)
+    bad[11], bad[:, 13] = True, True
+    assert not torch.isfinite(got[bad]).any() and torch.isfinite(got[~bad]).all()
+    rel = ((got.double() - want).abs() / (a.double().abs() @ b.double().abs()).clamp_min(1e-300))[~bad]
+    assert rel.max().item() < 8e-7
+    lib = _lib.lib()
+    ws = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    x = torch.zeros(64, 64, device="cuda")
+    ptr = lambda t, off=0: C.c_void_p(t.data_ptr() + off)
+    call = lambda A, lda, kmajor, M, N, K, nbytes: lib.dcq_gemm_f32_two_term(A, lda, kmajor, ptr(x), 64, ptr(x), 64, M, N, K,
+                                                                         1.0, 0.0, ptr(ws), nbytes, None)
+    # dcq_status: DCQ_ERR_UNSUPPORTED = -2, DCQ_ERR_ARGUMENT = -1
+    assert call(ptr(x), 64, 0, 64, 64, 48, 4096) == -2       # K not a multiple of 32
+    assert call(ptr(x), 64, 0, 64, 62, 32, 4096) == -2       # N not a multiple of 4
+    assert call(ptr(x), 64, 1, 62, 64, 32, 4096) == -2       # k-major A: M not a multiple of 4
+    assert call(ptr(x, 4), 64, 0, 32, 64, 32, 4096) == -2    # A not 16-byte aligned
+    assert call(ptr(x), 62, 0, 32, 64, 32, 4096) == -2       # leading dimension not a multiple of 4
+    assert call(ptr(x), 64, 0, 64, 64, 32, 256) == -1           # workspace below (M + N) * 4 bytes
+    assert call(ptr(x), 64, 0, 63, 64, 32, 4096) == 0                    # row-major A: any M
+
+
 @pytest.mark.parametrize("n,use_perm", [(128, False), (200, True), (640, True), (1000, False), (2048, True)])
 def test_inverse_factor_matches_float64(n, use_perm):
     """U from the blocked factorisation + triangular inverse vs the reference route

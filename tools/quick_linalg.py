@@ -33,7 +33,24 @@ if len(sys.argv) > 1 and sys.argv[1] == "err":
         t = c.clone().addmm_(am, b, alpha=-1.0)
         e_ours = ((out.double() - ref).abs() / scale).max().item()
         e_torch = ((t.double() - ref).abs() / scale).max().item()
-        print(f"M={M} N={N} K={K} at={at}: max |err| / (|A||B|)  ours {e_ours:.3e}  torch f32 {e_torch:.3e}", flush=True)
+        e_two = float("nan")
+        if M % 4 == 0 and N % 4 == 0:
+            out2 = c.clone()
+            gemm_f32(a, b, out2, alpha=-1.0, beta=1.0, a_transposed=at, two_term=True)
+            e_two = ((out2.double() - ref).abs() / scale).max().item()
+        print(f"M={M} N={N} K={K} at={at}: max |err| / (|A||B|)  ours {e_ours:.3e}  two-term {e_two:.3e}  torch f32 {e_torch:.3e}", flush=True)
+    # rows of A and columns of B spread over 12 decades: the per-row / per-column scales must keep every entry's accuracy
+    for (M, N, K, at) in [(1024, 1536, 512, False), (1024, 1536, 512, True)]:
+        a = torch.randn((K, M) if at else (M, K), device="cuda") * torch.logspace(-6, 6, M, device="cuda").reshape((1, M) if at else (M, 1))
+        b = torch.randn(K, N, device="cuda") * torch.logspace(6, -6, N, device="cuda").reshape(1, N)
+        am = a.T if at else a
+        ref = am.double() @ b.double()
+        scale = (am.double().abs() @ b.double().abs())
+        out2 = torch.empty(M, N, device="cuda")
+        gemm_f32(a, b, out2, a_transposed=at, two_term=True)
+        t = am @ b
+        print(f"graded M={M} N={N} K={K} at={at}: two-term {((out2.double() - ref).abs() / scale).max().item():.3e}  "
+              f"torch f32 {((t.double() - ref).abs() / scale).max().item():.3e}", flush=True)
     sys.exit(0)
 only_inv = len(sys.argv) > 1 and sys.argv[1] in ("inv", "big")
 sizes = [int(v) for v in sys.argv[2:]] if only_inv else (128, 1024, 4096, 14336)
@@ -45,8 +62,9 @@ for (M, N, K, at) in [(7168, 7168, 7168, False), (7168, 7168, 7168, True), (4096
     c = torch.randn(M, N, device="cuda")
     ms = timed(lambda: gemm_f32(a, b, c, alpha=-1.0, beta=1.0, a_transposed=at))
     ms_t = timed(lambda: c.addmm_(a.T if at else a, b, alpha=-1.0))
-    print(f"gemm M={M} N={N} K={K} at={at}: {ms*1e3:9.1f} us {2*M*N*K/ms/1e9:7.1f} TF/s | torch addmm {ms_t*1e3:9.1f} us "
-          f"{2*M*N*K/ms_t/1e9:7.1f} TF/s", flush=True)
+    ms_2 = timed(lambda: gemm_f32(a, b, c, alpha=-1.0, beta=1.0, a_transposed=at, two_term=True)) if K % 32 == 0 else float("nan")
+    print(f"gemm M={M} N={N} K={K} at={at}: {ms*1e3:9.1f} us {2*M*N*K/ms/1e9:7.1f} TF/s | two-term {ms_2*1e3:9.1f} us "
+          f"{2*M*N*K/ms_2/1e9:7.1f} TF/s | torch addmm {ms_t*1e3:9.1f} us {2*M*N*K/ms_t/1e9:7.1f} TF/s", flush=True)
 
 for n in sizes:
     x = torch.randn(2 * n, n, device="cuda")
