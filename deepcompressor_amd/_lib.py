@@ -124,6 +124,10 @@ def lib():
         handle.dcq_cholesky_workspace_bytes.restype = C.c_int64
         handle.dcq_linear_candidate_errors_workspace.argtypes = [_i64, _i64, _i32]
         handle.dcq_linear_candidate_errors_workspace.restype = C.c_int64
+        handle.dcq_gemm_f32_two_term_workspace_bytes.argtypes = [_i64, _i64, _i64]
+        handle.dcq_gemm_f32_two_term_workspace_bytes.restype = C.c_int64
+        handle.dcq_gptq_sweep_workspace_bytes.argtypes = [_i64, _i64, _i32]
+        handle.dcq_gptq_sweep_workspace_bytes.restype = C.c_int64
         handle.dcq_version.restype = C.c_char_p
         handle.dcq_last_error.restype = C.c_char_p
         _lib = handle

@@ -38,12 +38,13 @@ int try_launch_fused_int(const dcq_step& st, const void* x, int storage, int64_t
 // lean kernel for value-table (floating-point) dtypes without zero point, one or two scale levels (dcq_fused.hip)
 // float32 GEMM (dcq_gemm_f32) with the arithmetic path chosen by the caller: the float32 matrix instructions, or
 // three-term bf16 splits on the bf16 matrix pipe (same accuracy, other roundings); kGemmAuto picks by problem size.
-// `magnitudes`: NULL, or M + N words of scratch, with which a product on the split path uses two float16 terms per
-// operand (scaled per row of A and column of B) instead of three bfloat16 ones.
+// `scratch`: NULL, or two_term_scratch_bytes(M, N, K) bytes (256-byte aligned), with which a product on the split path
+// uses two float16 terms per operand (scaled per row of A and column of B) instead of three bfloat16 ones.
 enum { kGemmAuto = 0, kGemmFloat32 = 1, kGemmSplit = 2 };
 int gemm_f32_on_path(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, float alpha, float beta, hipStream_t stream, int path,
-                     unsigned* magnitudes = nullptr);
+                     unsigned char* scratch = nullptr);
+size_t two_term_scratch_bytes(int64_t M, int64_t N, int64_t K);
 
 int try_launch_fused_table(const dcq_step& st, const void* x, int storage, int64_t G, int64_t S, int has_ratio,
                            float ratio, const float* tensor_absmax, const dcq_rounding* level0, float level0_span,

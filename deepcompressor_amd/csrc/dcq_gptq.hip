@@ -1096,14 +1096,21 @@ int dcq_gptq_sweep_block(const dcq_step* step, float* W, int64_t ldw, int64_t R,
   return DCQ_OK;
 }
 
+int64_t dcq_gptq_sweep_workspace_bytes(int64_t R, int64_t C, int32_t lazy_blocks) {
+  if (R <= 0 || C <= 0 || lazy_blocks < 1) return 0;
+  return static_cast<int64_t>(two_term_scratch_bytes(R, C, static_cast<int64_t>(kSweepCols) * lazy_blocks));
+}
+
 int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64_t C, const float* U,
                    const float* scale, const float* zero, float zero_scalar, int32_t row_group_size,
                    int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
                    int32_t lazy_blocks, void* workspace, int64_t workspace_bytes, dcq_stream_t stream) {
   DCQ_REQUIRE(lazy_blocks >= 1 && lazy_blocks <= 64, DCQ_ERR_ARGUMENT, "lazy_blocks must be in [1, 64]");
   DCQ_REQUIRE(C > 0 && C < (1ll << 31), DCQ_ERR_ARGUMENT, "bad C");
-  DCQ_REQUIRE(workspace == nullptr || ((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0 && workspace_bytes >= (R + C) * 4),
-              DCQ_ERR_ARGUMENT, "the workspace, when given, holds (R + C) * 4 bytes, 4-byte aligned");
+  DCQ_REQUIRE(workspace == nullptr || ((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0 &&
+                                       workspace_bytes >= dcq_gptq_sweep_workspace_bytes(R, C, lazy_blocks)),
+              DCQ_ERR_ARGUMENT,
+              "the workspace, when given, holds dcq_gptq_sweep_workspace_bytes(R, C, lazy_blocks) bytes, 256-byte aligned");
   if (R == 0) return DCQ_OK;
   const int64_t group_cols = static_cast<int64_t>(kSweepCols) * lazy_blocks;
   for (int64_t g0 = 0; g0 < C; g0 += group_cols) {
@@ -1126,7 +1133,7 @@ int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64
       // holds (rows of one weight may be split over processes)
       const int path = C - g_end >= 2048 ? kGemmSplit : kGemmFloat32;
       const int rc = gemm_f32_on_path(Err, group_cols, 0, U + g0 * C + g_end, C, W + g_end, ldw, R, C - g_end, group_cols,
-                                      -1.0f, 1.0f, static_cast<hipStream_t>(stream), path, static_cast<unsigned*>(workspace));
+                                      -1.0f, 1.0f, static_cast<hipStream_t>(stream), path, static_cast<unsigned char*>(workspace));
       if (rc != DCQ_OK) return rc;
     }
   }

@@ -57,6 +57,9 @@ struct GemmParams {
   // two-term half-precision path only: bit patterns of max |A(m, :)| per row of C and max |B[:][n]| per column of C
   const unsigned* a_absmax;
   const unsigned* b_absmax;
+  // the operands as float16 term planes, one image per 128-wide tile and K step (split_planes_kernel)
+  const unsigned char* a_planes;
+  const unsigned char* b_planes;
 };
 
 // One 16-byte piece of a row: `FAST` pieces are whole and aligned; otherwise every element is guarded by `limit`
@@ -315,160 +318,10 @@ __device__ __forceinline__ void half_scale_of(unsigned absmax_bits, float& scale
 
 __device__ __forceinline__ int split_row_of(int s) { return 64 * (s >> 6) + 4 * (s & 15) + ((s >> 4) & 3); }
 
-template <bool A_KMAJOR, bool FAST, int PLANES>
-__device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned char* lds, int m0, int n0, int k_begin,
-                                                int nk) {
-  constexpr int kOperandBytes = split_operand_bytes(PLANES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const bool stages_a = tid < 128;  // uniform per wave
-  const int u = tid & 127;
-  // k-major operand: thread = (4 consecutive columns 4 q.., k chunk kc); row-major A: thread = piece u % 8 of 8 rows
-  float4 regs[2][8];  // two sets of staging registers, used in turn: K step kt + 2 is requested while kt is multiplied
-  const int q = u & 31, kc = u >> 5;
-  // two-term path: the scale of each row (row-major A) or column (k-major operand) this thread stages
-  float sc[8] = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
-  if constexpr (PLANES == 2) {
-    float unused;
-    if (stages_a && !A_KMAJOR) {
-#pragma unroll
-      for (int it = 0; it < 8; ++it)
-        half_scale_of(p.a_absmax[min(m0 + split_row_of(16 * it + (u >> 3)), p.M - 1)], sc[it], unused);
-    } else {
-      const unsigned* absmax = stages_a ? p.a_absmax : p.b_absmax;
-      const int c0 = (stages_a ? m0 : n0) + 4 * q, limit = stages_a ? p.M : p.N;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) half_scale_of(absmax[min(c0 + e, limit - 1)], sc[e], unused);
-    }
-  }
-  auto load_stage = [&](int kt, const int set) __attribute__((always_inline)) {
-    const int k0 = k_begin + kt * kSplitK;
-    if (stages_a && !A_KMAJOR) {
-      // 8 lanes read the 128 bytes of one row; a thread holds piece u % 8 of the rows 16 it + u / 8
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = min(m0 + split_row_of(16 * it + (u >> 3)), p.M - 1);
-        regs[set][it] = load_piece<FAST>(p.A + static_cast<int64_t>(row) * p.lda + k0, 4 * (u & 7), kSplitK);
-      }
-    } else {
-      const float* src = stages_a ? p.A : p.B;
-      const int64_t ld = stages_a ? p.lda : p.ldb;
-      const int c0 = (stages_a ? m0 : n0) + 4 * q, limit = stages_a ? p.M : p.N;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) regs[set][j] = load_piece<FAST>(src + static_cast<int64_t>(k0 + 8 * kc + j) * ld, c0, limit);
-    }
-  };
-  auto store_stage = [&](const int set) __attribute__((always_inline)) {
-    unsigned char* img = lds + (stages_a ? 0 : kOperandBytes);
-    if (stages_a && !A_KMAJOR) {
-      const int ck = (u & 7) >> 1;  // the piece's k chunk; its half of the chunk: u % 2
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int srow = 16 * it + (u >> 3);
-        const bool live = m0 + split_row_of(srow) < p.M;
-        const float4 v = live ? regs[set][it] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        unsigned char* at = img + ck * kSplitChunkBytes + (srow ^ ck) * 16 + (u & 1) * 8;
-        if constexpr (PLANES == 3) {
-          uint2 h, m, l;
-          split_pair(f32x2{v.x, v.y}, h.x, m.x, l.x);
-          split_pair(f32x2{v.z, v.w}, h.y, m.y, l.y);
-          *reinterpret_cast<uint2*>(at) = h;
-          *reinterpret_cast<uint2*>(at + kSplitPlaneBytes) = m;
-          *reinterpret_cast<uint2*>(at + 2 * kSplitPlaneBytes) = l;
-        } else {
-          uint2 h, l;
-          split_pair(f32x2{v.x * sc[it], v.y * sc[it]}, h.x, l.x);
-          split_pair(f32x2{v.z * sc[it], v.w * sc[it]}, h.y, l.y);
-          *reinterpret_cast<uint2*>(at) = h;
-          *reinterpret_cast<uint2*>(at + kSplitPlaneBytes) = l;
-        }
-      }
-    } else {
-      // rows (q % 16) + 16 c + 64 (q / 16), c = 0..3; kc only flips the two lowest bits of the row
-      unsigned char* at = img + kc * kSplitChunkBytes + (((q & 15) ^ kc) + 64 * (q >> 4)) * 16;
-      {
-        const float x[8] = {regs[set][0].x * sc[0], regs[set][1].x * sc[0], regs[set][2].x * sc[0], regs[set][3].x * sc[0],
-                            regs[set][4].x * sc[0], regs[set][5].x * sc[0], regs[set][6].x * sc[0], regs[set][7].x * sc[0]};
-        split_store<PLANES>(x, at);
-      }
-      {
-        const float x[8] = {regs[set][0].y * sc[1], regs[set][1].y * sc[1], regs[set][2].y * sc[1], regs[set][3].y * sc[1],
-                            regs[set][4].y * sc[1], regs[set][5].y * sc[1], regs[set][6].y * sc[1], regs[set][7].y * sc[1]};
-        split_store<PLANES>(x, at + 16 * 16);
-      }
-      {
-        const float x[8] = {regs[set][0].z * sc[2], regs[set][1].z * sc[2], regs[set][2].z * sc[2], regs[set][3].z * sc[2],
-                            regs[set][4].z * sc[2], regs[set][5].z * sc[2], regs[set][6].z * sc[2], regs[set][7].z * sc[2]};
-        split_store<PLANES>(x, at + 32 * 16);
-      }
-      {
-        const float x[8] = {regs[set][0].w * sc[3], regs[set][1].w * sc[3], regs[set][2].w * sc[3], regs[set][3].w * sc[3],
-                            regs[set][4].w * sc[3], regs[set][5].w * sc[3], regs[set][6].w * sc[3], regs[set][7].w * sc[3]};
-        split_store<PLANES>(x, at + 48 * 16);
-      }
-    }
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-  if (nk > 0) {
-    load_stage(0, 0);
-    if (nk > 1) load_stage(1, 1);
-    store_stage(0);
-  }
-  __syncthreads();
-  const int g = lane >> 4, j = lane & 15;
-  const unsigned char* fa = lds + g * kSplitChunkBytes + (64 * wr + (j ^ g)) * 16;
-  const unsigned char* fb = lds + kOperandBytes + g * kSplitChunkBytes + (64 * wc + (j ^ g)) * 16;
-  auto multiply_step = [&]() __attribute__((always_inline)) {
-    uint4 a[PLANES][4], b[PLANES][4];
-#pragma unroll
-    for (int pl = 0; pl < PLANES; ++pl)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[pl][i] = *reinterpret_cast<const uint4*>(fa + pl * kSplitPlaneBytes + i * 256);
-        b[pl][i] = *reinterpret_cast<const uint4*>(fb + pl * kSplitPlaneBytes + i * 256);
-      }
-    // smallest terms first
-    if constexpr (PLANES == 3) {
-      constexpr int pa[6] = {0, 2, 1, 0, 1, 0}, pb[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[pa[t]][i]),
-                                                                __builtin_bit_cast(bf16x8, b[pb[t]][n]), acc[i][n], 0, 0, 0);
-    } else {
-      constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[pa[t]][i]),
-                                                               __builtin_bit_cast(f16x8, b[pb[t]][n]), acc[i][n], 0, 0, 0);
-    }
-  };
-  // one K step: multiply the image of step kt, then replace it by step kt + 1 (register set `have`); set `next` takes kt + 2
-  auto step = [&](int kt, const int have, const int next) __attribute__((always_inline)) {
-    if (kt + 2 < nk) load_stage(kt + 2, next);
-    multiply_step();
-    __syncthreads();  // every wave has read this K step's image
-    if (kt + 1 < nk) store_stage(have);
-    __syncthreads();
-  };
-  for (int kt = 0; kt < nk; kt += 2) {
-    step(kt, 1, 0);
-    if (kt + 1 < nk) step(kt + 1, 0, 1);
-  }
-  // lane (g, j) of block (i, n) holds C[64 wr + 16 g + 4 r + i][64 wc + 4 j + n], r = 0..3
+// Result of one 128 x 128 tile: lane (g, j) of block (i, n) holds C[64 wr + 16 g + 4 r + i][64 wc + 4 j + n], r = 0..3
+template <int PLANES>
+__device__ __forceinline__ void split_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int wr, int wc,
+                                               int g, int j) {
   const bool whole = m0 + 128 <= p.M && n0 + 128 <= p.N && p.vec_c;  // uniform
   float back_b[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // two-term path: the scales are taken out again, exactly
   if constexpr (PLANES == 2) {
@@ -507,7 +360,127 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
     }
 }
 
-template <bool A_KMAJOR, int PLANES>
+template <bool A_KMAJOR, bool FAST>
+__device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned char* lds, int m0, int n0, int k_begin,
+                                                int nk) {
+  constexpr int kOperandBytes = split_operand_bytes(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const bool stages_a = tid < 128;  // uniform per wave
+  const int u = tid & 127;
+  // k-major operand: thread = (4 consecutive columns 4 q.., k chunk kc); row-major A: thread = piece u % 8 of 8 rows
+  float4 regs[2][8];  // two sets of staging registers, used in turn: K step kt + 2 is requested while kt is multiplied
+  const int q = u & 31, kc = u >> 5;
+  auto load_stage = [&](int kt, const int set) __attribute__((always_inline)) {
+    const int k0 = k_begin + kt * kSplitK;
+    if (stages_a && !A_KMAJOR) {
+      // 8 lanes read the 128 bytes of one row; a thread holds piece u % 8 of the rows 16 it + u / 8
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = min(m0 + split_row_of(16 * it + (u >> 3)), p.M - 1);
+        regs[set][it] = load_piece<FAST>(p.A + static_cast<int64_t>(row) * p.lda + k0, 4 * (u & 7), kSplitK);
+      }
+    } else {
+      const float* src = stages_a ? p.A : p.B;
+      const int64_t ld = stages_a ? p.lda : p.ldb;
+      const int c0 = (stages_a ? m0 : n0) + 4 * q, limit = stages_a ? p.M : p.N;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) regs[set][j] = load_piece<FAST>(src + static_cast<int64_t>(k0 + 8 * kc + j) * ld, c0, limit);
+    }
+  };
+  auto store_stage = [&](const int set) __attribute__((always_inline)) {
+    unsigned char* img = lds + (stages_a ? 0 : kOperandBytes);
+    if (stages_a && !A_KMAJOR) {
+      const int ck = (u & 7) >> 1;  // the piece's k chunk; its half of the chunk: u % 2
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int srow = 16 * it + (u >> 3);
+        const bool live = m0 + split_row_of(srow) < p.M;
+        const float4 v = live ? regs[set][it] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        unsigned char* at = img + ck * kSplitChunkBytes + (srow ^ ck) * 16 + (u & 1) * 8;
+        uint2 h, m, l;
+        split_pair(f32x2{v.x, v.y}, h.x, m.x, l.x);
+        split_pair(f32x2{v.z, v.w}, h.y, m.y, l.y);
+        *reinterpret_cast<uint2*>(at) = h;
+        *reinterpret_cast<uint2*>(at + kSplitPlaneBytes) = m;
+        *reinterpret_cast<uint2*>(at + 2 * kSplitPlaneBytes) = l;
+      }
+    } else {
+      // rows (q % 16) + 16 c + 64 (q / 16), c = 0..3; kc only flips the two lowest bits of the row
+      unsigned char* at = img + kc * kSplitChunkBytes + (((q & 15) ^ kc) + 64 * (q >> 4)) * 16;
+      {
+        const float x[8] = {regs[set][0].x, regs[set][1].x, regs[set][2].x, regs[set][3].x,
+                            regs[set][4].x, regs[set][5].x, regs[set][6].x, regs[set][7].x};
+        split_store<3>(x, at);
+      }
+      {
+        const float x[8] = {regs[set][0].y, regs[set][1].y, regs[set][2].y, regs[set][3].y,
+                            regs[set][4].y, regs[set][5].y, regs[set][6].y, regs[set][7].y};
+        split_store<3>(x, at + 16 * 16);
+      }
+      {
+        const float x[8] = {regs[set][0].z, regs[set][1].z, regs[set][2].z, regs[set][3].z,
+                            regs[set][4].z, regs[set][5].z, regs[set][6].z, regs[set][7].z};
+        split_store<3>(x, at + 32 * 16);
+      }
+      {
+        const float x[8] = {regs[set][0].w, regs[set][1].w, regs[set][2].w, regs[set][3].w,
+                            regs[set][4].w, regs[set][5].w, regs[set][6].w, regs[set][7].w};
+        split_store<3>(x, at + 48 * 16);
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  if (nk > 0) {
+    load_stage(0, 0);
+    if (nk > 1) load_stage(1, 1);
+    store_stage(0);
+  }
+  __syncthreads();
+  const int g = lane >> 4, j = lane & 15;
+  const unsigned char* fa = lds + g * kSplitChunkBytes + (64 * wr + (j ^ g)) * 16;
+  const unsigned char* fb = lds + kOperandBytes + g * kSplitChunkBytes + (64 * wc + (j ^ g)) * 16;
+  auto multiply_step = [&]() __attribute__((always_inline)) {
+    bf16x8 a[3][4], b[3][4];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fa + pl * kSplitPlaneBytes + i * 256));
+        b[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fb + pl * kSplitPlaneBytes + i * 256));
+      }
+    // smallest terms first
+    constexpr int pa[6] = {0, 2, 1, 0, 1, 0}, pb[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa[t]][i], b[pb[t]][n], acc[i][n], 0, 0, 0);
+  };
+  // one K step: multiply the image of step kt, then replace it by step kt + 1 (register set `have`); set `next` takes kt + 2
+  auto step = [&](int kt, const int have, const int next) __attribute__((always_inline)) {
+    if (kt + 2 < nk) load_stage(kt + 2, next);
+    multiply_step();
+    __syncthreads();  // every wave has read this K step's image
+    if (kt + 1 < nk) store_stage(have);
+    __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, 1, 0);
+    if (kt + 1 < nk) step(kt + 1, 0, 1);
+  }
+  split_epilogue<3>(p, acc, m0, n0, wr, wc, g, j);
+}
+
+template <bool A_KMAJOR>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(const GemmParams p) {
   extern __shared__ __align__(16) unsigned char gemm_smem[];
   int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
@@ -522,18 +495,215 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_split_kernel(const GemmP
   const int nk = k_end > k_begin ? (k_end - k_begin) / kSplitK : 0;
   const bool fast = p.vec_a && p.vec_b && n0 + 128 <= p.N && (!A_KMAJOR || m0 + 128 <= p.M);
   if (fast) {
-    gemm_split_tile<A_KMAJOR, true, PLANES>(p, gemm_smem, m0, n0, k_begin, nk);
+    gemm_split_tile<A_KMAJOR, true>(p, gemm_smem, m0, n0, k_begin, nk);
   } else {
-    gemm_split_tile<A_KMAJOR, false, PLANES>(p, gemm_smem, m0, n0, k_begin, nk);
+    gemm_split_tile<A_KMAJOR, false>(p, gemm_smem, m0, n0, k_begin, nk);
   }
 }
 
-template <bool A_KMAJOR, int PLANES>
+template <bool A_KMAJOR>
 static int launch_gemm_split(const GemmParams& p, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(p.tiles_m) * static_cast<unsigned>(p.tiles_n);
-  hipLaunchKernelGGL((gemm_split_kernel<A_KMAJOR, PLANES>), dim3(grid), dim3(kGemmThreads), split_lds_bytes(PLANES), s, p);
+  hipLaunchKernelGGL(gemm_split_kernel<A_KMAJOR>, dim3(grid), dim3(kGemmThreads), split_lds_bytes(3), s, p);
   DCQ_LAUNCH_CHECK("gemm_split_kernel launch");
   return DCQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The two-term path with the operands split ONCE, ahead of the product.  In the kernel above every workgroup converts
+// the operand tiles it stages, so a value of a 7168-wide product is scaled and split 56 times; and the conversions
+// share the vector pipe with the address arithmetic of the loads.  split_planes_kernel writes, for every 128-wide
+// tile of an operand and every K step of 32, the 16 KiB image that kernel would have put into LDS (2 planes x 4 chunks
+// of 8 x [row position][8 float16], rows permuted and swizzled as described above); gemm_planes_kernel then only
+// copies images into LDS (16-byte pieces, linear, two LDS buffers so one barrier per K step) and multiplies.
+// ---------------------------------------------------------------------------------------------
+constexpr int kImageBytes = 2 * kSplitPlaneBytes;  // one operand tile, one K step
+
+// `clip`: 1 = the operand is zero for k beyond the end of the tile's own 128-block (and those blocks may hold anything),
+// 2 = for k before its start.  Workgroup = two K steps of one tile.
+template <bool KMAJOR>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int64_t ld, int extent, int K,
+                                                           const unsigned* __restrict__ absmax, int clip,
+                                                           unsigned char* __restrict__ planes) {
+  const int ksteps = K / kSplitK;
+  const int t = blockIdx.x, ks = blockIdx.y * 2 + (threadIdx.x >> 7);
+  if (ks >= ksteps) return;
+  const int k0 = ks * kSplitK, c0 = t * 128;
+  if (clip == 1 && k0 >= c0 + 128) return;
+  if (clip == 2 && k0 + kSplitK <= c0) return;
+  unsigned char* img = planes + (static_cast<int64_t>(t) * ksteps + ks) * kImageBytes;
+  const int u = threadIdx.x & 127;
+  float unused;
+  if (KMAJOR) {
+    // thread = (4 consecutive columns 4 q .., k chunk kc)
+    const int q = u & 31, kc = u >> 5;
+    const int col = c0 + 4 * q;
+    const bool live = col < extent;  // extent is a multiple of 4
+    float sc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) half_scale_of(absmax[min(col + e, extent - 1)], sc[e], unused);
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = live ? *reinterpret_cast<const float4*>(src + static_cast<int64_t>(k0 + 8 * kc + j) * ld + col)
+                  : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    unsigned char* at = img + kc * kSplitChunkBytes + (((q & 15) ^ kc) + 64 * (q >> 4)) * 16;
+    {
+      const float x[8] = {v[0].x * sc[0], v[1].x * sc[0], v[2].x * sc[0], v[3].x * sc[0],
+                          v[4].x * sc[0], v[5].x * sc[0], v[6].x * sc[0], v[7].x * sc[0]};
+      split_store<2>(x, at);
+    }
+    {
+      const float x[8] = {v[0].y * sc[1], v[1].y * sc[1], v[2].y * sc[1], v[3].y * sc[1],
+                          v[4].y * sc[1], v[5].y * sc[1], v[6].y * sc[1], v[7].y * sc[1]};
+      split_store<2>(x, at + 16 * 16);
+    }
+    {
+      const float x[8] = {v[0].z * sc[2], v[1].z * sc[2], v[2].z * sc[2], v[3].z * sc[2],
+                          v[4].z * sc[2], v[5].z * sc[2], v[6].z * sc[2], v[7].z * sc[2]};
+      split_store<2>(x, at + 32 * 16);
+    }
+    {
+      const float x[8] = {v[0].w * sc[3], v[1].w * sc[3], v[2].w * sc[3], v[3].w * sc[3],
+                          v[4].w * sc[3], v[5].w * sc[3], v[6].w * sc[3], v[7].w * sc[3]};
+      split_store<2>(x, at + 48 * 16);
+    }
+  } else {
+    // 8 lanes read the 128 bytes of one row; a thread holds piece u % 8 of the rows at positions 16 it + u / 8
+    const int ck = (u & 7) >> 1;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int srow = 16 * it + (u >> 3);
+      const int row = c0 + split_row_of(srow);
+      const bool live = row < extent;
+      float scale;
+      half_scale_of(absmax[min(row, extent - 1)], scale, unused);
+      const float4 v = live ? *reinterpret_cast<const float4*>(src + static_cast<int64_t>(row) * ld + k0 + 4 * (u & 7))
+                            : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      uint2 h, l;
+      split_pair(f32x2{v.x * scale, v.y * scale}, h.x, l.x);
+      split_pair(f32x2{v.z * scale, v.w * scale}, h.y, l.y);
+      unsigned char* at = img + ck * kSplitChunkBytes + (srow ^ ck) * 16 + (u & 1) * 8;
+      *reinterpret_cast<uint2*>(at) = h;
+      *reinterpret_cast<uint2*>(at + kSplitPlaneBytes) = l;
+    }
+  }
+}
+
+constexpr int kPlanesLdsBytes = 2 * 2 * kImageBytes;  // two buffers of [A image | B image]: 64 KiB
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// a wave's fragments of one K step: 4 row blocks x 2 planes of each operand
+__device__ __forceinline__ void planes_read(const unsigned char* img, int frag_a, int frag_b, u32x4 (&a)[2][4],
+                                            u32x4 (&b)[2][4]) {
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[pl][i] = *reinterpret_cast<const u32x4*>(img + frag_a + pl * kSplitPlaneBytes + i * 256);
+      b[pl][i] = *reinterpret_cast<const u32x4*>(img + frag_b + pl * kSplitPlaneBytes + i * 256);
+    }
+}
+
+__device__ __forceinline__ void planes_multiply(f32x4 (&acc)[4][4], const u32x4 (&a)[2][4], const u32x4 (&b)[2][4]) {
+  constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};  // l h', h l', h h': smallest terms first
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[pa[t]][i]),
+                                                           __builtin_bit_cast(f16x8, b[pb[t]][n]), acc[i][n], 0, 0, 0);
+}
+
+__device__ __forceinline__ void planes_request(int image, int nk, const unsigned char* ga, const unsigned char* gb,
+                                               u32x4 (&ra)[4], u32x4 (&rb)[4]) {
+  // past the end the loads repeat the last image; nobody uses what they deliver
+  const int64_t at_image = static_cast<int64_t>(min(image, nk - 1)) * kImageBytes;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = *reinterpret_cast<const u32x4*>(ga + at_image + i * 4096);
+    rb[i] = *reinterpret_cast<const u32x4*>(gb + at_image + i * 4096);
+  }
+}
+
+// One K step of gemm_planes_kernel.  The register set (ra, rb) holds image kt + 1, requested three steps ago: it goes
+// into the LDS buffer that image kt - 1 has left (every wave read it before the barrier that ended step kt - 1), the
+// set is requested again for image kt + 4, and the step's own image is multiplied.
+__device__ __forceinline__ void planes_step(int kt, int nk, const unsigned char* ga, const unsigned char* gb,
+                                            unsigned char* lds, int tid, int frag_a, int frag_b, f32x4 (&acc)[4][4],
+                                            u32x4 (&ra)[4], u32x4 (&rb)[4]) {
+  unsigned char* at = lds + ((kt + 1) & 1) * 2 * kImageBytes + tid * 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<u32x4*>(at + i * 4096) = ra[i];
+    *reinterpret_cast<u32x4*>(at + kImageBytes + i * 4096) = rb[i];
+  }
+  planes_request(kt + 4, nk, ga, gb, ra, rb);
+  u32x4 a[2][4], b[2][4];
+  planes_read(lds + (kt & 1) * 2 * kImageBytes, frag_a, frag_b, a, b);
+  planes_multiply(acc, a, b);
+  __syncthreads();
+}
+
+// What bounds it: the LDS.  A K step moves 32 KiB into it and 64 KiB out of it per tile (every operand fragment is
+// read by two of the four waves), and 16-byte LDS accesses run at 64 bytes per cycle and compute unit: 1536 cycles
+// where the step's 192 matrix instructions need 768.  Measured 1790 cycles per tile and step (7168^3 in 2.0 ms,
+// 2.2 with the passes that prepare the operands); taking the matrix instructions out of the kernel changes nothing,
+// nor do fragment reads one step ahead, or two tiles per workgroup of 8 waves taking turns at the matrix pipe.
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_planes_kernel(const GemmParams p) {
+  extern __shared__ __align__(16) unsigned char gemm_smem[];
+  int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
+  if (p.k_below_m) tm = p.tiles_m - 1 - tm;  // longest reductions first (see gemm_f32_kernel)
+  if (p.k_below_n) tn = p.tiles_n - 1 - tn;
+  if (p.upper_only && tn < tm) return;
+  const int m0 = tm * 128, n0 = tn * 128;
+  int k_begin = 0, k_end = p.K;
+  if (p.k_above_m) k_begin = max(k_begin, m0 / kSplitK * kSplitK);
+  if (p.k_below_m) k_end = min(k_end, m0 + 128);
+  if (p.k_below_n) k_end = min(k_end, n0 + 128);
+  const int nk = k_end > k_begin ? (k_end - k_begin) / kSplitK : 0;
+  const int ksteps = p.K / kSplitK, ks0 = k_begin / kSplitK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int g = lane >> 4, j = lane & 15;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (nk > 0) {  // uniform over the workgroup
+    const unsigned char* ga = p.a_planes + (static_cast<int64_t>(tm) * ksteps + ks0) * kImageBytes + tid * 16;
+    const unsigned char* gb = p.b_planes + (static_cast<int64_t>(tn) * ksteps + ks0) * kImageBytes + tid * 16;
+    const int frag_a = g * kSplitChunkBytes + (64 * wr + (j ^ g)) * 16;
+    const int frag_b = kImageBytes + g * kSplitChunkBytes + (64 * wc + (j ^ g)) * 16;
+    u32x4 ra0[4], rb0[4], ra1[4], rb1[4], ra2[4], rb2[4];  // register set s holds the images 3 i + s, i = 1, 2, ...
+    planes_request(0, nk, ga, gb, ra0, rb0);
+    planes_request(1, nk, ga, gb, ra1, rb1);
+    planes_request(2, nk, ga, gb, ra2, rb2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(gemm_smem + tid * 16 + i * 4096) = ra0[i];
+      *reinterpret_cast<u32x4*>(gemm_smem + tid * 16 + kImageBytes + i * 4096) = rb0[i];
+    }
+    planes_request(3, nk, ga, gb, ra0, rb0);
+    __syncthreads();
+    // (the loop's body has no branch in it: with skipped steps falling through to the loop's end the compiler sees ways
+    // back to the top on which the youngest loads are the ones needed next, and waits for all loads in every step)
+    int kt = 0;
+    for (; kt + 3 <= nk; kt += 3) {
+      planes_step(kt, nk, ga, gb, gemm_smem, tid, frag_a, frag_b, acc, ra1, rb1);
+      planes_step(kt + 1, nk, ga, gb, gemm_smem, tid, frag_a, frag_b, acc, ra2, rb2);
+      planes_step(kt + 2, nk, ga, gb, gemm_smem, tid, frag_a, frag_b, acc, ra0, rb0);
+    }
+    if (kt < nk) {
+      planes_step(kt, nk, ga, gb, gemm_smem, tid, frag_a, frag_b, acc, ra1, rb1);
+      if (kt + 1 < nk) planes_step(kt + 1, nk, ga, gb, gemm_smem, tid, frag_a, frag_b, acc, ra2, rb2);
+    }
+  }
+  split_epilogue<2>(p, acc, m0, n0, wr, wc, g, j);
 }
 
 // Largest magnitudes for the two-term path, as float32 bit patterns (which order like the magnitudes; a NaN sorts
@@ -620,9 +790,59 @@ static int launch_absmax(GemmParams& p, bool a_kmajor, unsigned* absmax, hipStre
 
 // `path`: kGemmAuto picks by problem size (results of the two float32 tile sizes are bit-identical; the split path
 // rounds differently), kGemmFloat32 / kGemmSplit force one -- for callers whose results must not depend on M.
-// `absmax`: scratch of M + N words; when given, a product that takes the split path runs on two float16 terms per
-// operand (half the matrix instructions) instead of three bfloat16 terms.
-static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s, int path = kGemmAuto, unsigned* absmax = nullptr) {
+// Scratch of a two-term product: M + N words for the magnitudes, then the term planes of both operands.
+static size_t two_term_planes_bytes(int64_t M, int64_t N, int64_t K) {
+  return static_cast<size_t>((M + 127) / 128 + (N + 127) / 128) * static_cast<size_t>(K / kSplitK) * kImageBytes;
+}
+static size_t two_term_magnitude_bytes(int64_t M, int64_t N) { return static_cast<size_t>(M + N + 63) / 64 * 256; }
+size_t two_term_scratch_bytes(int64_t M, int64_t N, int64_t K) {
+  return two_term_magnitude_bytes(M, N) + two_term_planes_bytes(M, N, K);
+}
+
+// Magnitudes, planes and the product itself (p.vec_a / vec_b hold, N % 4 == 0, M % 4 == 0 for a k-major A).
+static int launch_gemm_two_term(GemmParams& p, bool a_kmajor, unsigned char* scratch, hipStream_t s) {
+  int rc = launch_absmax(p, a_kmajor, reinterpret_cast<unsigned*>(scratch), s);
+  if (rc != DCQ_OK) return rc;
+  const bool same = p.a_absmax == p.b_absmax;
+  const int ksteps = p.K / kSplitK;
+  unsigned char* planes_b = scratch + two_term_magnitude_bytes(p.M, p.N);
+  unsigned char* planes_a = same ? planes_b : planes_b + static_cast<size_t>(p.tiles_n) * ksteps * kImageBytes;
+  const unsigned ky = static_cast<unsigned>((ksteps + 1) / 2);
+  hipLaunchKernelGGL(split_planes_kernel<true>, dim3(static_cast<unsigned>(p.tiles_n), ky), dim3(256), 0, s, p.B, p.ldb, p.N,
+                     p.K, p.b_absmax, p.k_below_n ? 1 : 0, planes_b);
+  DCQ_LAUNCH_CHECK("split_planes_kernel launch");
+  if (a_kmajor && !same) {
+    hipLaunchKernelGGL(split_planes_kernel<true>, dim3(static_cast<unsigned>(p.tiles_m), ky), dim3(256), 0, s, p.A, p.lda,
+                       p.M, p.K, p.a_absmax, p.k_below_m ? 1 : 0, planes_a);
+    DCQ_LAUNCH_CHECK("split_planes_kernel launch");
+  } else if (!a_kmajor) {
+    hipLaunchKernelGGL(split_planes_kernel<false>, dim3(static_cast<unsigned>(p.tiles_m), ky), dim3(256), 0, s, p.A, p.lda,
+                       p.M, p.K, p.a_absmax, p.k_above_m ? 2 : (p.k_below_m ? 1 : 0), planes_a);
+    DCQ_LAUNCH_CHECK("split_planes_kernel launch");
+  }
+  p.a_planes = planes_a;
+  p.b_planes = planes_b;
+  static std::atomic<bool> configured[64];  // (set twice by racing first calls at worst: the attribute call is idempotent)
+  int dev = 0;
+  rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
+  if (rc != DCQ_OK) return rc;
+  if (dev < 0 || dev >= 64 || !configured[dev]) {
+    rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPlanesLdsBytes),
+                   "hipFuncSetAttribute(planes LDS)");
+    if (rc != DCQ_OK) return rc;
+    if (dev >= 0 && dev < 64) configured[dev] = true;
+  }
+  const unsigned grid = static_cast<unsigned>(p.tiles_m) * static_cast<unsigned>(p.tiles_n);
+  hipLaunchKernelGGL(gemm_planes_kernel, dim3(grid), dim3(kGemmThreads), kPlanesLdsBytes, s, p);
+  DCQ_LAUNCH_CHECK("gemm_planes_kernel launch");
+  return DCQ_OK;
+}
+
+// `scratch`: NULL, or two_term_scratch_bytes(M, N, K) bytes (256-byte aligned); when given, a product that takes the
+// split path runs on two float16 terms per operand (half the matrix instructions) instead of three bfloat16 terms.
+static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s, int path = kGemmAuto,
+                       unsigned char* scratch = nullptr) {
   GemmParams p = pin;
   if (p.M <= 0 || p.N <= 0) return DCQ_OK;
   p.vec_a = (reinterpret_cast<uintptr_t>(p.A) & 15u) == 0 && p.lda % 4 == 0;
@@ -636,14 +856,11 @@ static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s, int 
   const int T = split || big_tiles >= 512 ? 128 : 64;
   p.tiles_m = (p.M + T - 1) / T;
   p.tiles_n = (p.N + T - 1) / T;
-  // (the two-term path reads whole aligned pieces in its magnitude pass, and a k-major A clipped from below has no
-  // such pass)
-  if (split && absmax != nullptr && p.vec_a && p.vec_b && p.N % 4 == 0 && !(a_kmajor && (p.M % 4 != 0 || p.k_above_m))) {
-    const int rc = launch_absmax(p, a_kmajor, absmax, s);
-    if (rc != DCQ_OK) return rc;
-    return a_kmajor ? launch_gemm_split<true, 2>(p, s) : launch_gemm_split<false, 2>(p, s);
-  }
-  if (split) return a_kmajor ? launch_gemm_split<true, 3>(p, s) : launch_gemm_split<false, 3>(p, s);
+  // (the two-term path reads whole aligned pieces in its passes over the operands, and a k-major A clipped from
+  // below has no such pass)
+  if (split && scratch != nullptr && p.vec_a && p.vec_b && p.N % 4 == 0 && !(a_kmajor && (p.M % 4 != 0 || p.k_above_m)))
+    return launch_gemm_two_term(p, a_kmajor, scratch, s);
+  if (split) return a_kmajor ? launch_gemm_split<true>(p, s) : launch_gemm_split<false>(p, s);
   if (T == 64) return a_kmajor ? launch_gemm_variant<true, 64>(p, s) : launch_gemm_variant<false, 64>(p, s);
   return a_kmajor ? launch_gemm_variant<true, 128>(p, s) : launch_gemm_variant<false, 128>(p, s);
 }
@@ -1006,7 +1223,7 @@ struct CholPlan {
   int64_t np;
   int nblk;
   size_t a_bytes, x_bytes, t_bytes;
-  size_t m_bytes;  // row / column magnitudes of the operands of one large product
+  size_t s_bytes;  // scratch of one large product on the two-term path (magnitudes and term planes); 0: none is large
 };
 
 static CholPlan plan_chol(int64_t n) {
@@ -1017,7 +1234,8 @@ static CholPlan plan_chol(int64_t n) {
   c.x_bytes = c.a_bytes;
   const int64_t half = (c.nblk + 1) / 2 * kNb;
   c.t_bytes = static_cast<size_t>(half) * half * 4;
-  c.m_bytes = static_cast<size_t>(c.np) * 4;  // M + N of any product of the recursion is at most np
+  // M, N and K of every product of the recursion are at most `half`; the split path starts at 128 tiles
+  c.s_bytes = (half / 128) * (half / 128) >= 128 ? two_term_scratch_bytes(half, half, half) : 0;
   return c;
 }
 
@@ -1028,7 +1246,7 @@ static CholPlan plan_chol(int64_t n) {
 //     A22 -= R12^T R12                (upper triangle only; K = size of the first half, so C is touched once)
 //     [R22, X22] = recurse(A22)
 //     X12 = -X11 (R12 X22)
-static int factor_invert(float* A, float* X, float* T, unsigned* mags, int64_t np, int lo, int hi, int32_t* info,
+static int factor_invert(float* A, float* X, float* T, unsigned char* mags, int64_t np, int lo, int hi, int32_t* info,
                          hipStream_t s) {
   if (hi - lo == 1) {
     const int64_t off = (static_cast<int64_t>(lo) * kNb) * (np + 1);
@@ -1146,8 +1364,7 @@ int cholesky_inverse_upper_on(const float* H, int64_t n, const int64_t* perm, fl
 // pointer is ever handed to kernels and memsets.
 // ---------------------------------------------------------------------------------------------
 constexpr int kStaticCholMaxN = 2048;
-constexpr size_t kStaticCholBytes = 2ull * kStaticCholMaxN * kStaticCholMaxN * 4 +
-                                    1ull * (kStaticCholMaxN / 2) * (kStaticCholMaxN / 2) * 4 + kStaticCholMaxN * 4;
+constexpr size_t kStaticCholBytes = 2ull * kStaticCholMaxN * kStaticCholMaxN * 4 + 1ull * (kStaticCholMaxN / 2) * (kStaticCholMaxN / 2) * 4;
 static __device__ __align__(256) unsigned char scratch[kStaticCholBytes];  // 36 MiB per GPU, for the process's lifetime
 
 constexpr int kMaxDevices = 64;
@@ -1180,7 +1397,7 @@ namespace dcq {
 
 int gemm_f32_on_path(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, float alpha, float beta, hipStream_t stream, int path,
-                     unsigned* magnitudes) {
+                     unsigned char* scratch) {
   DCQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, DCQ_ERR_ARGUMENT, "negative size");
   if (M == 0 || N == 0) return DCQ_OK;
   DCQ_REQUIRE(A && B && C, DCQ_ERR_ARGUMENT, "NULL buffer");
@@ -1198,7 +1415,7 @@ int gemm_f32_on_path(const float* A, int64_t lda, int32_t a_kmajor, const float*
   g.K = static_cast<int32_t>(K);
   g.alpha = alpha;
   g.beta = beta;
-  return launch_gemm(g, a_kmajor != 0, stream, path, magnitudes);
+  return launch_gemm(g, a_kmajor != 0, stream, path, scratch);
 }
 
 }  // namespace dcq
@@ -1208,6 +1425,11 @@ extern "C" {
 int dcq_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
                  int64_t M, int64_t N, int64_t K, float alpha, float beta, dcq_stream_t stream) {
   return gemm_f32_on_path(A, lda, a_kmajor, B, ldb, C, ldc, M, N, K, alpha, beta, static_cast<hipStream_t>(stream), kGemmAuto, nullptr);
+}
+
+int64_t dcq_gemm_f32_two_term_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return static_cast<int64_t>(two_term_scratch_bytes(M, N, K));
 }
 
 int dcq_gemm_f32_two_term(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
@@ -1221,9 +1443,11 @@ int dcq_gemm_f32_two_term(const float* A, int64_t lda, int32_t a_kmajor, const f
               (long long)N, (long long)K);
   DCQ_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), DCQ_ERR_UNSUPPORTED, "size too large");
   DCQ_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(B) & 15u) == 0 && lda % 4 == 0 &&
-                  ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(workspace) & 3u) == 0,
+                  ldb % 4 == 0,
               DCQ_ERR_UNSUPPORTED, "A and B must be 16-byte aligned with leading dimensions that are multiples of 4");
-  DCQ_REQUIRE(workspace_bytes >= (M + N) * 4, DCQ_ERR_ARGUMENT, "workspace too small: (M + N) * 4 bytes are needed");
+  DCQ_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, DCQ_ERR_ARGUMENT, "workspace must be 256-byte aligned");
+  DCQ_REQUIRE(workspace_bytes >= dcq_gemm_f32_two_term_workspace_bytes(M, N, K), DCQ_ERR_ARGUMENT,
+              "workspace too small: dcq_gemm_f32_two_term_workspace_bytes(M, N, K) bytes are needed");
   GemmParams g{};
   g.A = A;
   g.lda = lda;
@@ -1236,13 +1460,13 @@ int dcq_gemm_f32_two_term(const float* A, int64_t lda, int32_t a_kmajor, const f
   g.K = static_cast<int32_t>(K);
   g.alpha = alpha;
   g.beta = beta;
-  return launch_gemm(g, a_kmajor != 0, static_cast<hipStream_t>(stream), kGemmSplit, static_cast<unsigned*>(workspace));
+  return launch_gemm(g, a_kmajor != 0, static_cast<hipStream_t>(stream), kGemmSplit, static_cast<unsigned char*>(workspace));
 }
 
 int64_t dcq_cholesky_workspace_bytes(int64_t n) {
   if (n <= 0) return 0;
   const CholPlan c = plan_chol(n);
-  return static_cast<int64_t>(c.a_bytes + c.x_bytes + c.t_bytes + c.m_bytes);
+  return static_cast<int64_t>(c.a_bytes + c.x_bytes + c.t_bytes + c.s_bytes);
 }
 
 int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U, void* workspace,
@@ -1279,7 +1503,7 @@ int cholesky_inverse_upper_on(const float* H, int64_t n, const int64_t* perm, fl
   float* A = reinterpret_cast<float*>(ws);
   float* X = reinterpret_cast<float*>(ws + c.a_bytes);
   float* T = reinterpret_cast<float*>(ws + c.a_bytes + c.x_bytes);
-  unsigned* mags = reinterpret_cast<unsigned*>(ws + c.a_bytes + c.x_bytes + c.t_bytes);
+  unsigned char* mags = c.s_bytes ? ws + c.a_bytes + c.x_bytes + c.t_bytes : nullptr;
   const int64_t np = c.np;
   int rc = hip_check(hipMemsetAsync(info, 0x7f, 4, s), "hipMemsetAsync(info)");  // 0x7f7f7f7f = "no failure yet"
   if (rc != DCQ_OK) return rc;

@@ -302,7 +302,7 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, alpha: float 
     raw = lambda t: C.c_void_p(t.data_ptr())  # strided views: the leading dimensions carry the layout
     engine._require_gpu(c)
     if two_term:
-        ws = _workspace(c.device, (M + N) * 4)
+        ws = _workspace(c.device, lib().dcq_gemm_f32_two_term_workspace_bytes(M, N, K))
         check(lib().dcq_gemm_f32_two_term(raw(a), a.stride(0), int(a_transposed), raw(b), b.stride(0), raw(c), c.stride(0),
                                           M, N, K, float(alpha), float(beta), ptr(ws), ws.numel(), stream_of(c.device)),
               "dcq_gemm_f32_two_term")
@@ -430,7 +430,8 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     # writes the far part of W LAZY_BLOCKS times less often.
     group_cols = SWEEP_COLUMNS * LAZY_BLOCKS
     err = torch.empty((R, group_cols), device=dev, dtype=torch.float32)
-    magnitudes = torch.empty(R + Cn, device=dev, dtype=torch.int32)  # scratch of the far updates' two-term products
+    # scratch of the far updates' two-term products (magnitudes and term planes of the errors and of U's rows)
+    scratch = torch.empty(lib().dcq_gptq_sweep_workspace_bytes(R, Cn, LAZY_BLOCKS), device=dev, dtype=torch.uint8)
     # The factorisation is enqueued, not waited for: the sweep goes into the stream right behind it, and only then is
     # the factorisation's flag read.  A failed attempt (a non-positive pivot: rare, U is garbage then and so is this
     # sweep's output) is repeated with more damping, as the reference does (gptq.py:209-233).
@@ -440,7 +441,7 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
         Wp = engine.gather_columns(W, perm, zero_columns=dead)  # dead channels zeroed, act-order (gptq.py:199-208)
         Q = torch.empty_like(Wp)  # the sweep writes every row and column
         check(lib().dcq_gptq_sweep(C.byref(step), ptr(Wp), Cn, R, Cn, ptr(U), ptr(s2), ptr(z2), z_scalar, rg_size,
-                                   cg_size, n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, ptr(magnitudes), magnitudes.numel() * 4,
+                                   cg_size, n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, ptr(scratch), scratch.numel(),
                                    stream_of(dev)),
               "dcq_gptq_sweep")
         if info is None:

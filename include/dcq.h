@@ -293,7 +293,7 @@ int dcq_selftest_division(const float* x, const float* s, float* fast, float* re
  * side in Err[R][128 * lazy_blocks]; columns inside such a group are updated after every block, the columns
  * right of it once per group with one product of depth 128 * lazy_blocks (the same sums as the reference's
  * per-block update; only the float32 summation order differs).  U is [C][C] with leading dimension C.
- * `workspace`: NULL, or (R + C) * 4 bytes (4-byte aligned) of scratch, with which the far updates of 2048 or more
+ * `workspace`: NULL, or dcq_gptq_sweep_workspace_bytes(R, C, lazy_blocks) bytes (256-byte aligned) of scratch, with which the far updates of 2048 or more
  * columns run as dcq_gemm_f32_two_term products (half the matrix instructions of the three-term path they take
  * otherwise, float32-GEMM accuracy either way; a row's result depends on the choice but never on R).
  * ------------------------------------------------------------------------------------------- */
@@ -335,6 +335,8 @@ int dcq_nonfinite_flags(const float* x, int64_t n, int32_t* flags, dcq_stream_t 
 int dcq_gather_columns(const void* src, int32_t storage, int64_t ld_src, int64_t R, int64_t C, const int64_t* index,
                        const uint8_t* zero_columns, float* dst, int64_t ld_dst, dcq_stream_t stream);
 
+int64_t dcq_gptq_sweep_workspace_bytes(int64_t R, int64_t C, int32_t lazy_blocks);
+
 int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64_t C, const float* U,
                    const float* scale, const float* zero, float zero_scalar, int32_t row_group_size,
                    int32_t col_group_size, int32_t col_groups, const int64_t* perm, float* Q, float* Err,
@@ -354,16 +356,18 @@ int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64
  * dcq_gemm_f32_two_term: the same product from two float16 terms per operand, for any size.  Each row of A and each
  * column of B is first scaled by the power of two that brings its largest magnitude into [2^14, 2^15) (the scales
  * are taken out of the result again, exactly), then every value is split into h = float16(v) and l = float16(v - h)
- * and the product accumulates h h' + h l' + l h' in float32: three float16 matrix instructions where the three-term
- * path needs six.  A term pair misses at most 2^-22 of its value or 2^-39 of the largest magnitude in its row or
- * column, whichever is larger, and the term left out is of that size too, so the error per element stays within
- * 3 * 2^-22 of sum |a||b| however short K is (measured: 4.7e-7 at K = 32; 1.4e-7 ... 2e-7 from K = 512 on, where a
- * float32 multiply-accumulate chain has 2.5e-7 ... 3.6e-7, also with rows and columns graded over twelve decades).  A row or column whose
- * largest magnitude is zero, denormal or not finite is left unscaled (non-finite values give non-finite results).
- * Requires 16-byte aligned A and B, lda and ldb multiples of 4, K a multiple of 32, N (and M when a_kmajor) a multiple
- * of 4 (DCQ_ERR_UNSUPPORTED otherwise); `workspace`: (M + N) * 4 bytes, 4-byte aligned, for the magnitudes.  No
- * reference counterpart beyond the float32 matmul it stands for; dcq_cholesky_inverse_upper's products of 128 or more
- * tiles and dcq_gptq_sweep's far updates run on it.
+ * (once, into scratch planes laid out for the product kernel) and the product accumulates h h' + h l' + l h' in
+ * float32: three float16 matrix instructions where the three-term path needs six.  A term pair misses at most 2^-22
+ * of its value or 2^-39 of the largest magnitude in its row or column, whichever is larger, and the term left out is
+ * of that size too, so the error per element stays within 3 * 2^-22 of sum |a||b| however short K is (measured:
+ * 4.7e-7 at K = 32; 1.4e-7 ... 2e-7 from K = 512 on, where a float32 multiply-accumulate chain has 2.5e-7 ...
+ * 3.6e-7, also with rows and columns graded over twelve decades).  A row or column whose largest magnitude is zero,
+ * denormal or not finite is left unscaled (non-finite values give non-finite results).  Requires 16-byte aligned A
+ * and B, lda and ldb multiples of 4, K a multiple of 32, N (and M when a_kmajor) a multiple of 4
+ * (DCQ_ERR_UNSUPPORTED otherwise); `workspace`: dcq_gemm_f32_two_term_workspace_bytes(M, N, K) bytes, 256-byte
+ * aligned, for the magnitudes and for the operands' term planes (about the size of the operands, padded to whole
+ * 128-wide tiles).  No reference counterpart beyond the float32 matmul it stands for; the products of 128 or more
+ * tiles of dcq_cholesky_inverse_upper and the far updates of dcq_gptq_sweep run on it.
  *
  * dcq_cholesky_inverse_upper: U[n][n] (upper triangular, row-major) with U^T U = S^-1 where
  *     S = P H' P^T + diag_add * I,   H' = H with zero diagonal entries set to 1 (gptq.py:199-201),
@@ -376,6 +380,8 @@ int dcq_gptq_sweep(const dcq_step* step, float* W, int64_t ldw, int64_t R, int64
  * ------------------------------------------------------------------------------------------- */
 int dcq_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
                  int64_t M, int64_t N, int64_t K, float alpha, float beta, dcq_stream_t stream);
+
+int64_t dcq_gemm_f32_two_term_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
 int dcq_gemm_f32_two_term(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, float* C, int64_t ldc,
                           int64_t M, int64_t N, int64_t K, float alpha, float beta, void* workspace, int64_t workspace_bytes,

@@ -151,19 +151,19 @@ def test_gemm_f32_two_term_special_rows_and_refusals():
     rel = ((got.double() - want).abs() / (a.double().abs() @ b.double().abs()).clamp_min(1e-300))[~bad]
     assert rel.max().item() < 8e-7
     lib = _lib.lib()
-    ws = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
     x = torch.zeros(64, 64, device="cuda")
     ptr = lambda t, off=0: C.c_void_p(t.data_ptr() + off)
     call = lambda A, lda, kmajor, M, N, K, nbytes: lib.dcq_gemm_f32_two_term(A, lda, kmajor, ptr(x), 64, ptr(x), 64, M, N, K,
                                                                          1.0, 0.0, ptr(ws), nbytes, None)
     # dcq_status: DCQ_ERR_UNSUPPORTED = -2, DCQ_ERR_ARGUMENT = -1
-    assert call(ptr(x), 64, 0, 64, 64, 48, 4096) == -2       # K not a multiple of 32
-    assert call(ptr(x), 64, 0, 64, 62, 32, 4096) == -2       # N not a multiple of 4
-    assert call(ptr(x), 64, 1, 62, 64, 32, 4096) == -2       # k-major A: M not a multiple of 4
-    assert call(ptr(x, 4), 64, 0, 32, 64, 32, 4096) == -2    # A not 16-byte aligned
-    assert call(ptr(x), 62, 0, 32, 64, 32, 4096) == -2       # leading dimension not a multiple of 4
-    assert call(ptr(x), 64, 0, 64, 64, 32, 256) == -1           # workspace below (M + N) * 4 bytes
-    assert call(ptr(x), 64, 0, 63, 64, 32, 4096) == 0                    # row-major A: any M
+    assert call(ptr(x), 64, 0, 64, 64, 48, 1 << 20) == -2       # K not a multiple of 32
+    assert call(ptr(x), 64, 0, 64, 62, 32, 1 << 20) == -2       # N not a multiple of 4
+    assert call(ptr(x), 64, 1, 62, 64, 32, 1 << 20) == -2       # k-major A: M not a multiple of 4
+    assert call(ptr(x, 4), 64, 0, 32, 64, 32, 1 << 20) == -2    # A not 16-byte aligned
+    assert call(ptr(x), 62, 0, 32, 64, 32, 1 << 20) == -2       # leading dimension not a multiple of 4
+    assert call(ptr(x), 64, 0, 64, 64, 32, 256) == -1        # workspace below dcq_gemm_f32_two_term_workspace_bytes
+    assert call(ptr(x), 64, 0, 63, 64, 32, 1 << 20) == 0                    # row-major A: any M
 
 
 @pytest.mark.parametrize("n,use_perm", [(128, False), (200, True), (640, True), (1000, False), (2048, True)])

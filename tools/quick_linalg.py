@@ -2,6 +2,10 @@
 import sys
 import torch
 sys.path.insert(0, ".")
+import os
+if os.environ.get("DCQ_LIB"):  # timing experiments: another build of the library
+    import deepcompressor_amd._lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["DCQ_LIB"])
 from deepcompressor_amd.quantizer.kernel.gptq import cholesky_inverse_upper, gemm_f32
 
 
