@@ -510,12 +510,13 @@ static int launch_gemm_split(const GemmParams& p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The two-term path with the operands split ONCE, ahead of the product.  In the kernel above every workgroup converts
-// the operand tiles it stages, so a value of a 7168-wide product is scaled and split 56 times; and the conversions
-// share the vector pipe with the address arithmetic of the loads.  split_planes_kernel writes, for every 128-wide
-// tile of an operand and every K step of 32, the 16 KiB image that kernel would have put into LDS (2 planes x 4 chunks
-// of 8 x [row position][8 float16], rows permuted and swizzled as described above); gemm_planes_kernel then only
-// copies images into LDS (16-byte pieces, linear, two LDS buffers so one barrier per K step) and multiplies.
+// The two-term path: the operands are split ONCE, ahead of the product.  In the three-term kernel above every
+// workgroup converts the operand tiles it stages, so a value of a 7168-wide product is split 56 times, and the
+// conversions share the vector pipe with the address arithmetic of the loads.  split_planes_kernel writes, for every
+// 128-wide tile of an operand and every K step of 32, a 16 KiB image in the layout above (2 planes x 4 chunks of 8 x
+// [row position][8 float16], rows permuted and swizzled): what a wave's lane reads as its fragment is 16 contiguous
+// bytes of it.  gemm_planes_kernel copies the A images into LDS (16-byte pieces, linear), reads the B fragments from
+// the images directly, and multiplies.
 // ---------------------------------------------------------------------------------------------
 constexpr int kImageBytes = 2 * kSplitPlaneBytes;  // one operand tile, one K step
 
@@ -590,21 +591,9 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   }
 }
 
-constexpr int kPlanesLdsBytes = 2 * 2 * kImageBytes;  // two buffers of [A image | B image]: 64 KiB
+constexpr int kPlanesLdsBytes = 2 * kImageBytes;  // two buffers of one A image: 32 KiB
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// a wave's fragments of one K step: 4 row blocks x 2 planes of each operand
-__device__ __forceinline__ void planes_read(const unsigned char* img, int frag_a, int frag_b, u32x4 (&a)[2][4],
-                                            u32x4 (&b)[2][4]) {
-#pragma unroll
-  for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a[pl][i] = *reinterpret_cast<const u32x4*>(img + frag_a + pl * kSplitPlaneBytes + i * 256);
-      b[pl][i] = *reinterpret_cast<const u32x4*>(img + frag_b + pl * kSplitPlaneBytes + i * 256);
-    }
-}
 
 __device__ __forceinline__ void planes_multiply(f32x4 (&acc)[4][4], const u32x4 (&a)[2][4], const u32x4 (&b)[2][4]) {
   constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};  // l h', h l', h h': smallest terms first
@@ -618,41 +607,51 @@ __device__ __forceinline__ void planes_multiply(f32x4 (&acc)[4][4], const u32x4 
                                                            __builtin_bit_cast(f16x8, b[pb[t]][n]), acc[i][n], 0, 0, 0);
 }
 
-__device__ __forceinline__ void planes_request(int image, int nk, const unsigned char* ga, const unsigned char* gb,
-                                               u32x4 (&ra)[4], u32x4 (&rb)[4]) {
-  // past the end the loads repeat the last image; nobody uses what they deliver
+// past the end the loads repeat the last image; nobody uses what they deliver
+__device__ __forceinline__ void planes_request_a(int image, int nk, const unsigned char* ga, u32x4 (&ra)[4]) {
   const int64_t at_image = static_cast<int64_t>(min(image, nk - 1)) * kImageBytes;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ra[i] = *reinterpret_cast<const u32x4*>(ga + at_image + i * 4096);
-    rb[i] = *reinterpret_cast<const u32x4*>(gb + at_image + i * 4096);
-  }
+  for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4*>(ga + at_image + i * 4096);
 }
 
-// One K step of gemm_planes_kernel.  The register set (ra, rb) holds image kt + 1, requested three steps ago: it goes
-// into the LDS buffer that image kt - 1 has left (every wave read it before the barrier that ended step kt - 1), the
-// set is requested again for image kt + 4, and the step's own image is multiplied.
-__device__ __forceinline__ void planes_step(int kt, int nk, const unsigned char* ga, const unsigned char* gb,
-                                            unsigned char* lds, int tid, int frag_a, int frag_b, f32x4 (&acc)[4][4],
-                                            u32x4 (&ra)[4], u32x4 (&rb)[4]) {
-  unsigned char* at = lds + ((kt + 1) & 1) * 2 * kImageBytes + tid * 16;
+// a wave's B fragments of one K step, straight from the image in global memory (it is in fragment order)
+__device__ __forceinline__ void planes_request_b(int image, int nk, const unsigned char* gb, u32x4 (&b)[2][4]) {
+  const int64_t at_image = static_cast<int64_t>(min(image, nk - 1)) * kImageBytes;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<u32x4*>(at + i * 4096) = ra[i];
-    *reinterpret_cast<u32x4*>(at + kImageBytes + i * 4096) = rb[i];
-  }
-  planes_request(kt + 4, nk, ga, gb, ra, rb);
-  u32x4 a[2][4], b[2][4];
-  planes_read(lds + (kt & 1) * 2 * kImageBytes, frag_a, frag_b, a, b);
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[pl][i] = *reinterpret_cast<const u32x4*>(gb + at_image + pl * kSplitPlaneBytes + i * 256);
+}
+
+// One K step of gemm_planes_kernel.  The register set `ra` holds A image kt + 1, requested two steps ago: it goes into
+// the LDS buffer that image kt - 1 has left (every wave read it before the barrier that ended step kt - 1) and the set
+// is requested again for image kt + 3; the A fragments of image kt come from LDS, the B fragments `b` of step kt were
+// requested two steps ago and their registers are requested again for step kt + 2.
+__device__ __forceinline__ void planes_step(int kt, int nk, const unsigned char* ga, const unsigned char* gb,
+                                            unsigned char* lds, int tid, int frag_a, f32x4 (&acc)[4][4], u32x4 (&ra)[4],
+                                            u32x4 (&b)[2][4]) {
+  unsigned char* at = lds + ((kt + 1) & 1) * kImageBytes + tid * 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(at + i * 4096) = ra[i];
+  planes_request_a(kt + 3, nk, ga, ra);
+  u32x4 a[2][4];
+  const unsigned char* img = lds + (kt & 1) * kImageBytes + frag_a;
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[pl][i] = *reinterpret_cast<const u32x4*>(img + pl * kSplitPlaneBytes + i * 256);
   planes_multiply(acc, a, b);
+  planes_request_b(kt + 2, nk, gb, b);
   __syncthreads();
 }
 
-// What bounds it: the LDS.  A K step moves 32 KiB into it and 64 KiB out of it per tile (every operand fragment is
-// read by two of the four waves), and 16-byte LDS accesses run at 64 bytes per cycle and compute unit: 1536 cycles
-// where the step's 192 matrix instructions need 768.  Measured 1790 cycles per tile and step (7168^3 in 2.0 ms,
-// 2.2 with the passes that prepare the operands); taking the matrix instructions out of the kernel changes nothing,
-// nor do fragment reads one step ahead, or two tiles per workgroup of 8 waves taking turns at the matrix pipe.
+// The A images go through LDS (two buffers, one barrier per K step); a wave reads its B fragments from global memory,
+// where the images are in fragment order already, which halves the LDS traffic and leaves room for three workgroups'
+// worth of LDS.  What bounds the kernel is the matrix pipe: 192 instructions of 16 x 16 x 32 per tile and K step at
+// the 32 cycles each that this chip sustains on 16-bit operands (its best dense 16-bit GEMM rate, 1.25 PFLOP/s, is
+// half the nominal one) are 1536 cycles per compute unit; measured 1750, and the same within 5 % with both operands
+// through LDS, with neither (all fragments from global memory, no barrier), with the fragments read one step ahead,
+// with one or three images in flight, and with two tiles per 8-wave workgroup taking turns at the matrix pipe.
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_planes_kernel(const GemmParams p) {
   extern __shared__ __align__(16) unsigned char gemm_smem[];
   int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;
@@ -676,32 +675,33 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_planes_kernel(const Gemm
     for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   if (nk > 0) {  // uniform over the workgroup
     const unsigned char* ga = p.a_planes + (static_cast<int64_t>(tm) * ksteps + ks0) * kImageBytes + tid * 16;
-    const unsigned char* gb = p.b_planes + (static_cast<int64_t>(tn) * ksteps + ks0) * kImageBytes + tid * 16;
+    const unsigned char* gb = p.b_planes + (static_cast<int64_t>(tn) * ksteps + ks0) * kImageBytes +
+                              g * kSplitChunkBytes + (64 * wc + (j ^ g)) * 16;
     const int frag_a = g * kSplitChunkBytes + (64 * wr + (j ^ g)) * 16;
-    const int frag_b = kImageBytes + g * kSplitChunkBytes + (64 * wc + (j ^ g)) * 16;
-    u32x4 ra0[4], rb0[4], ra1[4], rb1[4], ra2[4], rb2[4];  // register set s holds the images 3 i + s, i = 1, 2, ...
-    planes_request(0, nk, ga, gb, ra0, rb0);
-    planes_request(1, nk, ga, gb, ra1, rb1);
-    planes_request(2, nk, ga, gb, ra2, rb2);
+    u32x4 ra0[4], ra1[4];        // A image 2 i + s on its way to LDS in set s
+    u32x4 b0[2][4], b1[2][4];    // B fragments of step 2 i + s in set s
+    // the requests in the order the loop leaves them in at its end (A image kt + 1, B step kt, A image kt + 2, B step
+    // kt + 1), pinned: where the order on entry differs from the one around the loop the compiler waits for all loads
+    planes_request_a(0, nk, ga, ra0);
+    __builtin_amdgcn_sched_barrier(0);
+    planes_request_a(1, nk, ga, ra1);
+    __builtin_amdgcn_sched_barrier(0);
+    planes_request_b(0, nk, gb, b0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(gemm_smem + tid * 16 + i * 4096) = ra0[i];
-      *reinterpret_cast<u32x4*>(gemm_smem + tid * 16 + kImageBytes + i * 4096) = rb0[i];
-    }
-    planes_request(3, nk, ga, gb, ra0, rb0);
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(gemm_smem + tid * 16 + i * 4096) = ra0[i];
+    planes_request_a(2, nk, ga, ra0);
+    __builtin_amdgcn_sched_barrier(0);
+    planes_request_b(1, nk, gb, b1);
     __syncthreads();
     // (the loop's body has no branch in it: with skipped steps falling through to the loop's end the compiler sees ways
     // back to the top on which the youngest loads are the ones needed next, and waits for all loads in every step)
     int kt = 0;
-    for (; kt + 3 <= nk; kt += 3) {
-      planes_step(kt, nk, ga, gb, gemm_smem, tid, frag_a, frag_b, acc, ra1, rb1);
-      planes_step(kt + 1, nk, ga, gb, gemm_smem, tid, frag_a, frag_b, acc, ra2, rb2);
-      planes_step(kt + 2, nk, ga, gb, gemm_smem, tid, frag_a, frag_b, acc, ra0, rb0);
+    for (; kt + 2 <= nk; kt += 2) {
+      planes_step(kt, nk, ga, gb, gemm_smem, tid, frag_a, acc, ra1, b0);
+      planes_step(kt + 1, nk, ga, gb, gemm_smem, tid, frag_a, acc, ra0, b1);
     }
-    if (kt < nk) {
-      planes_step(kt, nk, ga, gb, gemm_smem, tid, frag_a, frag_b, acc, ra1, rb1);
-      if (kt + 1 < nk) planes_step(kt + 1, nk, ga, gb, gemm_smem, tid, frag_a, frag_b, acc, ra2, rb2);
-    }
+    if (kt < nk) planes_step(kt, nk, ga, gb, gemm_smem, tid, frag_a, acc, ra1, b0);
   }
   split_epilogue<2>(p, acc, m0, n0, wr, wc, g, j);
 }
@@ -822,17 +822,6 @@ static int launch_gemm_two_term(GemmParams& p, bool a_kmajor, unsigned char* scr
   }
   p.a_planes = planes_a;
   p.b_planes = planes_b;
-  static std::atomic<bool> configured[64];  // (set twice by racing first calls at worst: the attribute call is idempotent)
-  int dev = 0;
-  rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
-  if (rc != DCQ_OK) return rc;
-  if (dev < 0 || dev >= 64 || !configured[dev]) {
-    rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPlanesLdsBytes),
-                   "hipFuncSetAttribute(planes LDS)");
-    if (rc != DCQ_OK) return rc;
-    if (dev >= 0 && dev < 64) configured[dev] = true;
-  }
   const unsigned grid = static_cast<unsigned>(p.tiles_m) * static_cast<unsigned>(p.tiles_n);
   hipLaunchKernelGGL(gemm_planes_kernel, dim3(grid), dim3(kGemmThreads), kPlanesLdsBytes, s, p);
   DCQ_LAUNCH_CHECK("gemm_planes_kernel launch");
