@@ -60,13 +60,16 @@ def _orthonormalize(x: torch.Tensor) -> torch.Tensor:
     """Columns of x [n][k] orthonormalized by two rounds of Cholesky QR (x <- x R^-1 with R^T R = x^T x): everything
     large is a float64 matrix-core product, the k x k factorisations are the only small dense routines."""
     eye = torch.eye(x.shape[1], dtype=x.dtype, device=x.device)
+    given, failed = x, None
     for _ in range(2):
         gram = _split_k_f64(x, x, a_transposed=True)
         gram = (gram + gram.t()) * 0.5
         r, info = torch.linalg.cholesky_ex(gram, upper=True)
-        if int(info.item()) != 0:  # columns (numerically) dependent: the slow but unconditional route
-            return torch.linalg.qr(x).Q
+        failed = info if failed is None else failed | info
         x = _split_k_f64(x, torch.linalg.solve_triangular(r, eye, upper=True), splits=1)
+    # both rounds are queued before the host looks at the factorisations' flags (one read instead of two waits)
+    if int(failed.item()) != 0:  # columns (numerically) dependent: the slow but unconditional route
+        return torch.linalg.qr(given).Q
     return x
 
 
