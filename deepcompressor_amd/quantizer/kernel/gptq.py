@@ -29,6 +29,9 @@ __all__ = ["QuantGptqConfig", "QuantGptqKernel", "gptq_quantize", "hessian_accum
            "prepare_hessians", "clear_hessian_cache", "cholesky_inverse_upper", "gemm_f32"]
 
 LAZY_BLOCKS = 4  # sweep blocks per far-column update
+# the far updates of 2048 and more columns as two-float16-term products (``dcq_gemm_f32_two_term``; the sweep is then
+# handed the scratch they need); False: three bfloat16 terms, no scratch.  Float32-GEMM accuracy either way.
+TWO_TERM_UPDATES = True
 SWEEP_COLUMNS = 128  # columns per sweep launch; the result does not depend on the block width (only fp order does)
 
 
@@ -431,7 +434,8 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
     group_cols = SWEEP_COLUMNS * LAZY_BLOCKS
     err = torch.empty((R, group_cols), device=dev, dtype=torch.float32)
     # scratch of the far updates' two-term products (magnitudes and term planes of the errors and of U's rows)
-    scratch = torch.empty(lib().dcq_gptq_sweep_workspace_bytes(R, Cn, LAZY_BLOCKS), device=dev, dtype=torch.uint8)
+    scratch = (torch.empty(lib().dcq_gptq_sweep_workspace_bytes(R, Cn, LAZY_BLOCKS), device=dev, dtype=torch.uint8)
+               if TWO_TERM_UPDATES else None)
     # The factorisation is enqueued, not waited for: the sweep goes into the stream right behind it, and only then is
     # the factorisation's flag read.  A failed attempt (a non-positive pivot: rare, U is garbage then and so is this
     # sweep's output) is repeated with more damping, as the reference does (gptq.py:209-233).
@@ -441,7 +445,7 @@ def gptq_quantize(tensor: torch.Tensor, *, view_shape: torch.Size, quant_dtype: 
         Wp = engine.gather_columns(W, perm, zero_columns=dead)  # dead channels zeroed, act-order (gptq.py:199-208)
         Q = torch.empty_like(Wp)  # the sweep writes every row and column
         check(lib().dcq_gptq_sweep(C.byref(step), ptr(Wp), Cn, R, Cn, ptr(U), ptr(s2), ptr(z2), z_scalar, rg_size,
-                                   cg_size, n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, ptr(scratch), scratch.numel(),
+                                   cg_size, n_cg, ptr(perm), ptr(Q), ptr(err), LAZY_BLOCKS, ptr(scratch), 0 if scratch is None else scratch.numel(),
                                    stream_of(dev)),
               "dcq_gptq_sweep")
         if info is None:

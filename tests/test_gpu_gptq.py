@@ -358,6 +358,29 @@ def test_gptq_ragged_columns_and_progressive():
         assert e_gptq < e_rtn, (cname, e_gptq, e_rtn)
 
 
+def test_gptq_far_updates_with_and_without_scratch(monkeypatch):
+    """dcq_gptq_sweep with its optional workspace (far updates as two-term products) and without it (three-term
+    products): two float32-accurate roundings of the same sums, so the codes agree but for the rare weight that sits
+    on a rounding boundary, and the layer outputs agree to the GPTQ bar."""
+    from deepcompressor_amd.quantizer.kernel import gptq as gptq_mod
+
+    g = torch.Generator().manual_seed(77)
+    rows, cols, tokens = 96, 4096, 4608
+    w = (torch.randn(rows, cols, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    x = (torch.randn(tokens, cols, generator=g) * torch.exp(0.5 * torch.randn(cols, generator=g))).to(torch.bfloat16).cuda()
+    q = build_quantizer(FQ.meta["cases"]["uint4_post_g128_f16s"])
+    kern = QuantGptqConfig(damp_percentage=0.01, block_size=128, num_inv_tries=250, hessian_block_size=512)
+    cache = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_cached=1, num_total=1, num_samples=tokens)
+    outs = []
+    for two_term in (True, False):
+        monkeypatch.setattr(gptq_mod, "TWO_TERM_UPDATES", two_term)
+        outs.append(q.quantize(w, kernel=kern, inputs=cache, return_with_quant=True))
+    same = (outs[0].qdata == outs[1].qdata).float().mean().item()
+    assert same >= 0.999, same
+    y0, y1 = x.float() @ outs[0].data.float().T, x.float() @ outs[1].data.float().T
+    assert ((y0 - y1).abs().max() / y0.abs().max()).item() <= 1e-3
+
+
 @pytest.mark.parametrize("rows,cols,tokens", [(640, 768, 3000), (384, 3072, 4096)])
 def test_gptq_row_shards_equal_unsharded(rows, cols, tokens):
     """Rows are independent given the shared Hessian: quantizing row slabs separately (what each rank does when one
