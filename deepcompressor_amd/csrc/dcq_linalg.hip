@@ -841,7 +841,8 @@ static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s, int 
   const int64_t big_tiles = static_cast<int64_t>((p.M + 127) / 128) * ((p.N + 127) / 128);
   // the bf16-split kernel from 128 tiles on: alone it only pays from ~512 (n = 14336 inverse factor 28.1 -> 27.9 ms), but
   // beside other streams' kernels its shorter run per product does (112 -> 110.5 ms per Llama-3-8B layer step)
-  const bool split = p.K % kSplitK == 0 && (path == kGemmSplit || (path == kGemmAuto && big_tiles >= 128));
+  // (K = 0: nothing to split, and no grid for the passes over K; the float32 kernel writes beta * C)
+  const bool split = p.K > 0 && p.K % kSplitK == 0 && (path == kGemmSplit || (path == kGemmAuto && big_tiles >= 128));
   const int T = split || big_tiles >= 512 ? 128 : 64;
   p.tiles_m = (p.M + T - 1) / T;
   p.tiles_n = (p.N + T - 1) / T;

@@ -164,6 +164,10 @@ def test_gemm_f32_two_term_special_rows_and_refusals():
     assert call(ptr(x), 62, 0, 32, 64, 32, 1 << 20) == -2       # leading dimension not a multiple of 4
     assert call(ptr(x), 64, 0, 64, 64, 32, 256) == -1        # workspace below dcq_gemm_f32_two_term_workspace_bytes
     assert call(ptr(x), 64, 0, 63, 64, 32, 1 << 20) == 0                    # row-major A: any M
+    # K = 0: an empty sum, C = beta * C
+    c = torch.full((64, 64), 3.0, device="cuda")
+    assert lib.dcq_gemm_f32_two_term(ptr(x), 64, 0, ptr(x), 64, ptr(c), 64, 64, 64, 0, 1.0, 0.5, ptr(ws), 1 << 20, None) == 0
+    assert (c == 1.5).all()
 
 
 @pytest.mark.parametrize("n,use_perm", [(128, False), (200, True), (640, True), (1000, False), (2048, True)])
