@@ -188,6 +188,9 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
     sweeps start on a stream of their own as soon as that group's Hessian is there.  ``hessian_hook(channels)`` is
     called right before each of those Hessians is enqueued (a measurement hook); it may return a pair of
     ``torch.cuda.Event(enable_timing=True)``, which are then recorded around that Hessian's matrix-core launches.
+    When no scale state dict is asked for, the weights of a group are quantized as one weight stacked along the output
+    rows (``_quantize_stacked``: rows are independent given the Hessian, so the results are the same bit for bit, and
+    one sweep stands where one per linear stood).
 
     ``world`` > 1 (no counterpart in the reference either): ONE layer split over the ``world`` processes of the default
     process group, one per GPU.  Every rank passes the same modules (full weights) and the cache of ITS share of the
@@ -303,7 +306,8 @@ def _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, la
         for i in indices:
             torch.cuda.current_stream().wait_event(ready[i])
             parts.append(_quantize_layer_weights(order[i], config, quantizer_state_dict, layer_cache,
-                                                 return_with_scale_state_dict, develop_dtype, host_copies=pending))
+                                                 return_with_scale_state_dict, develop_dtype, host_copies=pending,
+                                                 stack=True))
         return parts
 
     results = run_on_streams([lambda b=b: run_bucket(b) for b in buckets], device=device,
@@ -320,8 +324,90 @@ def _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, la
                                                           len(names))))
 
 
+def _stack_ranges(ranges: list, rows: list[int]):
+    """The dynamic ranges of several weights as the range of the weights stacked along their rows, or None when they
+    do not stack: every weight must bring the same kind of range (nothing, a number per tensor, or per-group tensors
+    whose leading extent is the weight's number of row groups)."""
+    if all(r is None for r in ranges):
+        return None
+    if any(r is None for r in ranges):
+        return False
+    ranges = [(r,) if isinstance(r, DynamicRange) else tuple(r) for r in ranges]
+    if len({len(r) for r in ranges}) != 1:
+        return False
+    stacked = []
+    for step in zip(*ranges):
+        if all(r is None for r in step):
+            stacked.append(None)
+            continue
+        if any(r is None for r in step):
+            return False
+        parts = {}
+        for field_name in ("min", "max", "ratio"):
+            values = [getattr(r, field_name) for r in step]
+            if all(v is None for v in values):
+                parts[field_name] = None
+                continue
+            if any(v is None for v in values):
+                return False
+            tensors = [v for v in values if isinstance(v, torch.Tensor)]
+            if not tensors:
+                if len(set(float(v) for v in values)) == 1:
+                    parts[field_name] = values[0]  # the same number everywhere
+                    continue
+                return False  # different numbers per tensor: no per-group shape to spread them over
+            template = tensors[0]
+            if template.ndim < 2 or any(isinstance(v, torch.Tensor) and (v.ndim != template.ndim or v.shape[1:] != template.shape[1:])
+                                        for v in values):
+                return False
+            pieces = []
+            for v, n in zip(values, rows):
+                if not isinstance(v, torch.Tensor):
+                    v = torch.full((n, *template.shape[1:]), float(v), dtype=template.dtype, device=template.device)
+                if v.shape[0] != n:  # row groups taller than one row, or a per-tensor value: not stacked here
+                    return False
+                pieces.append(v)
+            parts[field_name] = torch.cat(pieces, dim=0)
+        stacked.append(DynamicRange(**parts))
+    return tuple(stacked)
+
+
+def _quantize_stacked(entries, quantizers, layer_cache) -> bool:
+    """Weights fed by the same activations, quantized by the same kind of quantizer, as ONE weight stacked along the
+    output rows (no counterpart in the reference; same results: every row of a weight is quantized on its own given the
+    Hessian, per row group for the scales).  One sweep -- a serial chain of small kernels whose length hardly depends on
+    the number of rows -- then stands where one per weight stood.  False: the weights do not stack, nothing was done."""
+    weights = [e.module.weight.data for e in entries]
+    first = weights[0]
+    if any(w.ndim != 2 or w.shape[1] != first.shape[1] or w.dtype != first.dtype or w.device != first.device
+           for w in weights):
+        return False
+    q0 = quantizers[0]
+    if any(q.config is not q0.config or q.develop_dtype != q0.develop_dtype or q.channels_dim != q0.channels_dim
+           or q.range_bound != q0.range_bound or q.quant_range != q0.quant_range or q.scale is not None
+           or q.zero is not None for q in quantizers):
+        return False
+    if any(shape[0] != 1 for shape in q0.config.group_shapes):  # groups must not reach over rows
+        return False
+    kernel = q0.kernel
+    if kernel is None or any(hasattr(kernel, "is_enabled_for") and not kernel.is_enabled_for(q.key) for q in quantizers):
+        return False
+    rows = [w.shape[0] for w in weights]
+    ranges = _stack_ranges([q.dynamic_range for q in quantizers], rows)
+    if ranges is False:
+        return False
+    result = q0.quantize(torch.cat(weights, dim=0), inputs=layer_cache[entries[0].name].inputs.front(),
+                         dynamic_range=ranges, return_with_dequant=True, return_with_quant=False)
+    at = 0
+    for e, n in zip(entries, rows):
+        e.module.weight.data = result.data[at:at + n]
+        at += n
+    return True
+
+
 def _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache, return_with_scale_state_dict,
-                            develop_dtype, host_copies: list | None = None) -> dict[str, torch.Tensor | float | None]:
+                            develop_dtype, host_copies: list | None = None,
+                            stack: bool = False) -> dict[str, torch.Tensor | float | None]:
     # Ranges searched here stay on the device for the second pass; their host copies for ``quantizer_state_dict``
     # (the contents of wgts.pt) are taken after the last kernel of the stage is enqueued, so that no search is waited
     # for before the work behind it is queued.  ``host_copies``: a list that receives those pending copies as
@@ -340,7 +426,18 @@ def _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache, 
             searched[e.name] = quantizer
     scale_state_dict: dict[str, torch.Tensor | float | None] = {}
     zeros: list[tuple[str, torch.Tensor]] = []
-    for e in entries:
+    stacked = False
+    if stack and len(entries) > 1 and layer_cache and not return_with_scale_state_dict:
+        # ``stack``: the caller vouches that the entries share their cached inputs
+        quantizers = []
+        for e in entries:
+            quantizer = searched.get(e.name) or LlmWeightQuantizer(config, develop_dtype=develop_dtype, key=e.key)
+            if e.name not in searched and quantizer.is_enabled():
+                quantizer.load_state_dict(quantizer_state_dict[e.name], device=e.module.weight.device)
+            quantizers.append(quantizer)
+        if all(q.is_enabled() for q in quantizers):
+            stacked = _quantize_stacked(entries, quantizers, layer_cache)
+    for e in entries if not stacked else ():
         quantizer = searched.get(e.name) or LlmWeightQuantizer(config, develop_dtype=develop_dtype, key=e.key)
         if not quantizer.is_enabled():
             continue

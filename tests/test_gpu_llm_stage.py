@@ -191,6 +191,52 @@ def test_weight_stage_on_streams_equals_the_serial_stage():
         assert torch.equal(a.module.weight.data, b.module.weight.data), a.name
 
 
+def test_weight_stage_stacks_the_weights_of_a_group(monkeypatch):
+    """Without a scale state dict to fill, the piped stage quantizes the linears that share their cached inputs as one
+    weight stacked along the output rows (one GPTQ call per group instead of one per linear): the weights it leaves in
+    the modules are bit-equal to the serial stage's, and so are the searched ranges it stores."""
+    from deepcompressor_amd.quantizer.kernel import gptq as gptq_mod
+
+    tag = "gptq_r_rtn"
+    m = LS.meta[tag]
+    g = torch.Generator().manual_seed(12)
+    serial, piped = build_layer(tag), build_layer(tag)
+    shared, cache = {}, {}
+    for e in serial:
+        c = e.module.in_features
+        if c not in shared:
+            x = (torch.randn(4, 256, c, generator=g) * torch.exp(0.7 * torch.randn(c, generator=g))).to(torch.float16).cuda()
+            shared[c] = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_cached=1, num_total=1,
+                                    num_samples=1024, orig_device=x.device)
+        cache[e.name] = IOTensorsCache(inputs=TensorsCache(shared[c]))
+    config = stage_config(m["case"], kernel_gptq=QuantGptqConfig())
+    calls = []
+    real = gptq_mod.gptq_quantize
+    monkeypatch.setattr(gptq_mod, "gptq_quantize", lambda tensor, **kw: (calls.append(tuple(tensor.shape)), real(tensor, **kw))[1])
+    want_state, got_state = {}, {}
+    quantize_layer_weights(serial, config, want_state, layer_cache=cache)
+    assert len(calls) == len(serial)
+    calls.clear()
+    quantize_layer_weights(piped, config, got_state, layer_cache=cache, streams=3)
+    assert len(shared) < len(serial), "the fixture must have linears that share their inputs"
+    assert len(calls) == len(shared), calls
+    assert sorted(r for r, _ in calls) != sorted(e.module.out_features for e in serial)
+    for a, b in zip(serial, piped):
+        assert torch.equal(a.module.weight.data, b.module.weight.data), a.name
+    assert list(got_state) == list(want_state) or sorted(got_state) == sorted(want_state)
+    def same(a, b):
+        if isinstance(a, torch.Tensor):
+            return isinstance(b, torch.Tensor) and torch.equal(a.cpu(), b.cpu())
+        if isinstance(a, dict):
+            return isinstance(b, dict) and list(a) == list(b) and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, (list, tuple)):
+            return isinstance(b, (list, tuple)) and len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return a == b
+
+    for name in want_state:
+        assert same(want_state[name], got_state[name]), name
+
+
 def test_activation_stage_calibrates_reloads_and_hooks():
     """smoothquant-static style: dynamic per-token int8 inputs (nothing to store) and static per-tensor int8 outputs
     (the stored range is the largest magnitude in the cache); acts.pt entries reload into the same behaviour."""
