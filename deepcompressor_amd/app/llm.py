@@ -310,8 +310,14 @@ def _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, la
                                                  stack=True))
         return parts
 
+    # The first bucket holds the longest pipeline (down_proj's: its Hessian is the first and by far the largest, its
+    # factorisation and sweep the longest chains), and since the groups are quantized as stacked weights the others
+    # finish a few milliseconds before it: its stream gets the higher priority (A/B, six pairs on two boxes: 100.9-103.4
+    # -> 99.3-102.1 ms per Llama-3-8B layer, -1.5 ms on average; before the stacking the same switch only moved time
+    # from one path to the other).
+    prio = [-1] + [0] * (len(buckets) - 1)
     results = run_on_streams([lambda b=b: run_bucket(b) for b in buckets], device=device,
-                             after=[ready[b[0]] for b in buckets])
+                             after=[ready[b[0]] for b in buckets], priorities=prio)
     for copy in pending:
         copy()
     merged: dict[str, torch.Tensor | float | None] = {}
