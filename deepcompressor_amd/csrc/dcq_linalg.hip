@@ -1214,6 +1214,11 @@ struct CholPlan {
   int nblk;
   size_t a_bytes, x_bytes, t_bytes;
   size_t s_bytes;  // scratch of one large product on the two-term path (magnitudes and term planes); 0: none is large
+  // R12 of a node stays in scratch of its own until the node is done (nothing outside the node reads it): one block
+  // per recursion depth, since the second half's recursion runs while the node's R12 is still needed
+  static constexpr int kMaxDepth = 24;
+  size_t r_offset[kMaxDepth];  // bytes, from the start of the R12 scratch
+  size_t r_bytes;
 };
 
 static CholPlan plan_chol(int64_t n) {
@@ -1226,18 +1231,28 @@ static CholPlan plan_chol(int64_t n) {
   c.t_bytes = static_cast<size_t>(half) * half * 4;
   // M, N and K of every product of the recursion are at most `half`; the split path starts at 128 tiles
   c.s_bytes = (half / 128) * (half / 128) >= 128 ? two_term_scratch_bytes(half, half, half) : 0;
+  // a node of `size` blocks at depth d has m1 = ceil(size / 2) and m2 <= m1 blocks; sizes at most halve (rounded up)
+  c.r_bytes = 0;
+  int size = c.nblk;
+  for (int d = 0; d < CholPlan::kMaxDepth; ++d) {
+    c.r_offset[d] = c.r_bytes;
+    const int64_t m1 = static_cast<int64_t>((size + 1) / 2) * kNb;
+    if (size > 2) c.r_bytes += static_cast<size_t>(m1) * m1 * 4;  // (leaves and pairs keep R12 to themselves)
+    size = (size + 1) / 2;
+  }
   return c;
 }
 
 // Factor and invert the diagonal range [lo, hi) of blocks:  A (upper, in place) -> R with R^T R = A, and
 // X = R^-1 (upper; X starts zeroed so triangular operands read zeros below their diagonal).  Recursive halves:
 //     [R11, X11] = recurse(A11)
-//     R12 = X11^T A12                 (triangular solve as a GEMM with the inverse that is needed anyway)
+//     R12 = X11^T A12                 (triangular solve as a GEMM with the inverse that is needed anyway; kept in
+//                                      scratch: only this node reads it, so A keeps A12 and no copy is needed)
 //     A22 -= R12^T R12                (upper triangle only; K = size of the first half, so C is touched once)
 //     [R22, X22] = recurse(A22)
 //     X12 = -X11 (R12 X22)
-static int factor_invert(float* A, float* X, float* T, unsigned char* mags, int64_t np, int lo, int hi, int32_t* info,
-                         hipStream_t s) {
+static int factor_invert(float* A, float* X, float* T, unsigned char* mags, unsigned char* r12_scratch, const CholPlan& plan,
+                         int depth, int64_t np, int lo, int hi, int32_t* info, hipStream_t s) {
   if (hi - lo == 1) {
     const int64_t off = (static_cast<int64_t>(lo) * kNb) * (np + 1);
     hipLaunchKernelGGL(panel_factor_kernel, dim3(1), dim3(kPanelThreads), 0, s, A + off, np, X + off, np, info, lo * kNb);
@@ -1264,15 +1279,19 @@ static int factor_invert(float* A, float* X, float* T, unsigned char* mags, int6
   const int m1 = (mid - lo) * kNb, m2 = (hi - mid) * kNb;
   const int64_t o1 = static_cast<int64_t>(lo) * kNb, o2 = static_cast<int64_t>(mid) * kNb;
   float* a12 = A + o1 * np + o2;
-  int rc = factor_invert(A, X, T, mags, np, lo, mid, info, s);
+  int rc = factor_invert(A, X, T, mags, r12_scratch, plan, depth + 1, np, lo, mid, info, s);
   if (rc != DCQ_OK) return rc;
-  {  // R12 = X11^T A12 -> T, then copied back (a GEMM cannot overwrite an operand other blocks still read)
+  // R12 [m1][m2] lives in this depth's scratch block: nothing outside the node reads it (its place in A keeps A12),
+  // and it must outlast the recursion on the second half, which uses T and the deeper blocks
+  DCQ_REQUIRE(depth < CholPlan::kMaxDepth, DCQ_ERR_UNSUPPORTED, "recursion deeper than planned");
+  float* r12 = reinterpret_cast<float*>(r12_scratch + plan.r_offset[depth]);
+  {  // R12 = X11^T A12
     GemmParams g{};
     g.A = X + o1 * np + o1;  // k-major operand: A'(m, k) = X11[k][m], zero for k > m
     g.lda = np;
     g.B = a12;
     g.ldb = np;
-    g.C = T;
+    g.C = r12;
     g.ldc = m2;
     g.M = m1;
     g.N = m2;
@@ -1282,17 +1301,13 @@ static int factor_invert(float* A, float* X, float* T, unsigned char* mags, int6
     g.k_below_m = 1;
     rc = launch_gemm(g, true, s, kGemmAuto, mags);
     if (rc != DCQ_OK) return rc;
-    rc = hip_check(hipMemcpy2DAsync(a12, np * 4, T, static_cast<size_t>(m2) * 4, static_cast<size_t>(m2) * 4, m1,
-                                    hipMemcpyDeviceToDevice, s),
-                   "hipMemcpy2DAsync(R12)");
-    if (rc != DCQ_OK) return rc;
   }
   {  // A22 -= R12^T R12 (both operands are the rows of R12)
     GemmParams g{};
-    g.A = a12;
-    g.lda = np;
-    g.B = a12;
-    g.ldb = np;
+    g.A = r12;
+    g.lda = m2;
+    g.B = r12;
+    g.ldb = m2;
     g.C = A + o2 * np + o2;
     g.ldc = np;
     g.M = m2;
@@ -1304,12 +1319,12 @@ static int factor_invert(float* A, float* X, float* T, unsigned char* mags, int6
     rc = launch_gemm(g, true, s, kGemmAuto, mags);
     if (rc != DCQ_OK) return rc;
   }
-  rc = factor_invert(A, X, T, mags, np, mid, hi, info, s);
+  rc = factor_invert(A, X, T, mags, r12_scratch, plan, depth + 1, np, mid, hi, info, s);
   if (rc != DCQ_OK) return rc;
   {  // T = R12 X22 (X22 upper: k <= n)
     GemmParams g{};
-    g.A = a12;
-    g.lda = np;
+    g.A = r12;
+    g.lda = m2;
     g.B = X + o2 * np + o2;
     g.ldb = np;
     g.C = T;
@@ -1354,8 +1369,11 @@ int cholesky_inverse_upper_on(const float* H, int64_t n, const int64_t* perm, fl
 // pointer is ever handed to kernels and memsets.
 // ---------------------------------------------------------------------------------------------
 constexpr int kStaticCholMaxN = 2048;
-constexpr size_t kStaticCholBytes = 2ull * kStaticCholMaxN * kStaticCholMaxN * 4 + 1ull * (kStaticCholMaxN / 2) * (kStaticCholMaxN / 2) * 4;
-static __device__ __align__(256) unsigned char scratch[kStaticCholBytes];  // 36 MiB per GPU, for the process's lifetime
+// matrix, inverse, the product scratch of half the order, and the R12 blocks of the three recursion depths above a pair
+constexpr size_t kStaticCholBytes = 2ull * kStaticCholMaxN * kStaticCholMaxN * 4 + 1ull * (kStaticCholMaxN / 2) * (kStaticCholMaxN / 2) * 4 +
+                                    (1ull * (kStaticCholMaxN / 2) * (kStaticCholMaxN / 2) + 1ull * (kStaticCholMaxN / 4) * (kStaticCholMaxN / 4) +
+                                     1ull * (kStaticCholMaxN / 8) * (kStaticCholMaxN / 8)) * 4;
+static __device__ __align__(256) unsigned char scratch[kStaticCholBytes];  // 41.25 MiB per GPU, for the process's lifetime
 
 constexpr int kMaxDevices = 64;
 static void* g_scratch_ptr[kMaxDevices] = {};
@@ -1456,7 +1474,7 @@ int dcq_gemm_f32_two_term(const float* A, int64_t lda, int32_t a_kmajor, const f
 int64_t dcq_cholesky_workspace_bytes(int64_t n) {
   if (n <= 0) return 0;
   const CholPlan c = plan_chol(n);
-  return static_cast<int64_t>(c.a_bytes + c.x_bytes + c.t_bytes + c.s_bytes);
+  return static_cast<int64_t>(c.a_bytes + c.x_bytes + c.t_bytes + c.s_bytes + c.r_bytes);
 }
 
 int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, float diag_add, float* U, void* workspace,
@@ -1476,6 +1494,8 @@ int dcq_cholesky_inverse_upper_static(const float* H, int64_t n, const int64_t* 
               "dcq_cholesky_inverse_upper with a caller-provided workspace",
               (long long)n, kStaticCholMaxN);
   DCQ_REQUIRE(H && U && info, DCQ_ERR_ARGUMENT, "NULL buffer");
+  DCQ_REQUIRE(static_cast<size_t>(dcq_cholesky_workspace_bytes(n)) <= kStaticCholBytes, DCQ_ERR_UNSUPPORTED,
+              "the built-in scratch is smaller than the workspace n = %lld needs", (long long)n);
   void* ws = nullptr;
   const int rc = static_scratch_of_current_device(&ws);
   if (rc != DCQ_OK) return rc;
@@ -1516,7 +1536,7 @@ int cholesky_inverse_upper_on(const float* H, int64_t n, const int64_t* perm, fl
   // halves of the diagonal blocks must read as zero.  Nothing ever reads a block strictly below the diagonal.
   hipLaunchKernelGGL(zero_diagonal_blocks_kernel, dim3(static_cast<unsigned>(c.nblk)), dim3(256), 0, s, X, np);
   DCQ_LAUNCH_CHECK("zero_diagonal_blocks_kernel launch");
-  rc = factor_invert(A, X, T, mags, np, 0, c.nblk, info, s);
+  rc = factor_invert(A, X, T, mags, ws + c.a_bytes + c.x_bytes + c.t_bytes + c.s_bytes, c, 0, np, 0, c.nblk, info, s);
   if (rc != DCQ_OK) return rc;
   hipLaunchKernelGGL(flip_transpose_kernel, dim3(static_cast<unsigned>((n + 31) / 32), static_cast<unsigned>((n + 31) / 32)),
                      dim3(256), 0, s, X, np, U, n);

@@ -394,7 +394,7 @@ int dcq_cholesky_inverse_upper(const float* H, int64_t n, const int64_t* perm, f
 
 /* dcq_cholesky_inverse_upper_static: the same routine for callers that cannot allocate device memory or pass a
  * workspace -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
- * counterpart in the reference.  The workspace is a 36 MiB array built into the library (one copy per GPU, held until
+ * counterpart in the reference.  The workspace is a 41.25 MiB array built into the library (one copy per GPU, held until
  * the process ends), so n is limited to 2048 (DCQ_ERR_UNSUPPORTED beyond); nothing is allocated or freed.  Same
  * kernels and results as dcq_cholesky_inverse_upper, bit for bit.  All calls on one GPU share that array: calls that
  * overlap on one GPU (different streams or threads) race and must be serialised by the caller.  The first call on a
