@@ -9,11 +9,22 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dcq.h"
 
 namespace dcq {
 
 constexpr int kWave = 64;
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // host-side error reporting

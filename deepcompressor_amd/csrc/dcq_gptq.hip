@@ -101,14 +101,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
 template <int ST>
 __device__ __forceinline__ f32x4 mfma_16x16x32(const uint4& a, const uint4& b, f32x4 c) {
   if constexpr (ST == DCQ_BF16) {

@@ -857,14 +857,17 @@ static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s, int 
 
 // =============================================================================================
 // Diagonal block.  Cholesky elimination on the augmented block [A | I] in registers: after the 128 pivots the left
-// part is R11 (upper, R11^T R11 = A) and the right part is R11^-T, whose transpose X11 = R11^-1 is written into the
-// inverse matrix.  One workgroup of 2 x 16 x 16 threads, each owning an 8 x 8 sub-block of one part.
+// part is R11 (upper, R11^T R11 = A) and the right part is Y = R11^-T, whose transpose X11 = R11^-1 is written into
+// the inverse matrix.  One workgroup of 2 x 16 x 16 threads: waves 0-3 hold the A part, waves 4-7 the Y part, and
+// thread (ty, tx) of a part owns its elements (ty + 16 i, tx + 16 c), i, c < 8 -- rows and columns dealt out
+// cyclically, so that the work left shrinks for all threads alike as the pivots advance.
 //
-// The pivots are taken 8 at a time (the 8 rows of one thread row), with two barriers per group instead of one per
-// pivot.  With D the group's 8 x 8 diagonal block and D = L L^T:
-//   1. the thread that holds D factors it and forms W = L^-1 (8 x 8, lower) in registers          -> LDS
-//   2. the threads of the group's row replace their rows by W x rows (the rows' final values)      -> LDS
-//   3. every thread below subtracts (column r of the final rows) x (final rows) from its rows r.
+// The pivots are taken 8 at a time, with two barriers per group instead of one per pivot.  With D the group's 8 x 8
+// diagonal block and D = R^T R:
+//   1. the owners of the group's 8 rows put them into LDS as they stand
+//   2. 256 threads, one per column of [A | Y]: each factors D for itself (R and 1 / diag R in registers) and solves
+//      R^T f = (its column of the 8 rows) by forward substitution: the rows' final values                -> LDS
+//   3. every row below subtracts (its entries in the 8 pivot columns) x (final rows): a rank-8 update.
 // The strict lower triangle of the left part is never used (it collects garbage and is written as zero).
 // info: 1-based global index of the first non-positive pivot (atomicMin: the earliest failure wins); the
 // arithmetic then continues on NaNs, which is harmless (no data-dependent addressing).
@@ -873,128 +876,151 @@ constexpr int kPanelThreads = 512;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct PanelLds {
-  float rows[8][2][kNb];  // the group's final rows: [row][A part | Y part][column]
-  float wmat[8][8];       // W = L^-1 of the group's diagonal block
+  float raw[8][2][kNb];   // the group's pivot rows as they stand: [row][A part | Y part][column]
+  float rows[8][2][kNb];  // ... and their final values
 };
+
+// The 8 x 8 diagonal block D = R^T R of a pivot group (upper triangle of `d` used): R (upper) and 1 / R[k][k].
+__device__ __forceinline__ void factor_8x8(const float (&d)[8][8], float (&R)[8][8], float (&inv)[8], int32_t* info,
+                                           int32_t first_index, bool report) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float s = d[k][k];
+#pragma unroll
+    for (int i = 0; i < k; ++i) s = __builtin_fmaf(-R[i][k], R[i][k], s);
+    if (report && !(s > 0.0f)) atomicMin(info, first_index + k + 1);
+    float r = __builtin_amdgcn_rsqf(s);
+    r = r * (1.5f - 0.5f * s * r * r);  // one Newton step: full float32 accuracy
+    inv[k] = r;
+    R[k][k] = s * r;
+#pragma unroll
+    for (int c = k + 1; c < 8; ++c) {
+      float t = d[k][c];
+#pragma unroll
+      for (int i = 0; i < k; ++i) t = __builtin_fmaf(-R[i][k], R[i][c], t);
+      R[k][c] = t * r;
+    }
+  }
+}
+
+// The two pivot groups whose rows lie in row band I0 (rows 16 I0 .. 16 I0 + 15).  Thread (part, ty, tx) owns the
+// elements (ty + 16 i, tx + 16 c), i, c < 8, of its part: rows and columns are dealt out cyclically, so that what is
+// left to update shrinks for every thread alike as the pivots advance -- the row bands above I0 and, in the A part,
+// the column bands left of it (in the Y part: right of it) are skipped by the whole workgroup, at compile time.
+template <int I0>
+__device__ __forceinline__ void panel_groups(f32x2 (&Z)[8][4], PanelLds& lds, int32_t* info, int32_t index_base, int tid) {
+  const int tx = tid & 15, ty = (tid >> 4) & 15, part = tid >> 8;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    const int o = 8 * half, p0 = 16 * I0 + o;  // pivots p0 .. p0 + 7: thread rows / columns o .. o + 7 of band I0
+    // 1. the pivot rows as they stand
+    if (ty >= o && ty < o + 8) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) lds.raw[ty - o][part][tx + 16 * c] = Z[I0][c >> 1][c & 1];
+    }
+    __syncthreads();
+    // 2. waves 0-3 (one per SIMD), one column of [A | Y] per thread: the factor R of the diagonal block, computed by
+    //    every thread for itself (the same chain of dependent operations whether one thread runs it or 256), then the
+    //    column's entries of the final rows R^-T x rows
+    if (tid < 256) {
+      float d[8][8], R[8][8], inv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int c = k; c < 8; ++c) d[k][c] = lds.raw[k][0][p0 + c];
+      factor_8x8(d, R, inv, info, index_base + p0, tid == 0);
+      // the column's entries of the final rows: R^T f = raw by forward substitution (rows of the A part become R,
+      // rows of the Y part R^-T so far)
+      const int pj = tid >> 7, col = tid & 127;
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float t = lds.raw[k][pj][col];
+#pragma unroll
+        for (int i = 0; i < k; ++i) t = __builtin_fmaf(-R[i][k], f[i], t);
+        f[k] = t * inv[k];
+        lds.rows[k][pj][col] = f[k];
+      }
+    }
+    __syncthreads();
+    // 3. the pivot rows take their final values; every row below subtracts (its entries in the pivot columns) x
+    //    (final rows).  In band I0 only the rows below the group take part (none for the band's second group).
+    if (ty >= o && ty < o + 8) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) Z[I0][c >> 1][c & 1] = lds.rows[ty - o][part][tx + 16 * c];
+    }
+    // column bands that can be non-zero and are still needed: A part I0 .. 7, Y part 0 .. I0 (a pair of bands per h)
+    auto update = [&](auto lo_const, auto hi_const) __attribute__((always_inline)) {
+      constexpr int lo = decltype(lo_const)::value, hi = decltype(hi_const)::value;
+      const bool band_live = ty >= o + 8;  // rows of band I0 below the group
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        f32x2 rc[4];
+#pragma unroll
+        for (int h = lo; h < hi; ++h)
+          rc[h] = f32x2{lds.rows[k][part][tx + 16 * (2 * h)], lds.rows[k][part][tx + 16 * (2 * h + 1)]};
+        static_for<8>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if constexpr (i >= I0) {
+            if (i > I0 || band_live) {
+              const float m = -lds.rows[k][0][ty + 16 * i];
+              const f32x2 mm = {m, m};
+#pragma unroll
+              for (int h = lo; h < hi; ++h) Z[i][h] = __builtin_elementwise_fma(mm, rc[h], Z[i][h]);
+            }
+          }
+        });
+      }
+    };
+    if (part == 0) {
+      update(std::integral_constant<int, I0 / 2>{}, std::integral_constant<int, 4>{});
+    } else {
+      update(std::integral_constant<int, 0>{}, std::integral_constant<int, I0 / 2 + 1>{});
+    }
+    // no barrier here: `raw` is rewritten before the next group's first barrier and was last read before this
+    // group's second; `rows` is rewritten after the next group's first barrier, which every reader above has passed
+  }
+}
 
 __device__ __forceinline__ void panel_factor(float* a, int64_t lda, float* x, int64_t ldx, int32_t* info,
                                              int32_t index_base, PanelLds& lds) {
-  float (&rows)[8][2][kNb] = lds.rows;
-  float (&wmat)[8][8] = lds.wmat;
   const int tid = threadIdx.x, tx = tid & 15, ty = (tid >> 4) & 15;
   const int part = tid >> 8;  // waves 0-3 hold the A part, waves 4-7 the Y part
   f32x2 Z[8][4];
 #pragma unroll
-  for (int ii = 0; ii < 8; ++ii) {
-    const int r = 8 * ty + ii;
-    const float4 v0 = *reinterpret_cast<const float4*>(a + r * lda + 8 * tx);
-    const float4 v1 = *reinterpret_cast<const float4*>(a + r * lda + 8 * tx + 4);
-    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  for (int i = 0; i < 8; ++i) {
+    const int r = ty + 16 * i;
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      const int c = 8 * tx + cc;
-      Z[ii][cc >> 1][cc & 1] = part == 0 ? (c >= r ? v[cc] : 0.0f) : (c == r ? 1.0f : 0.0f);
+    for (int c = 0; c < 8; ++c) {
+      const int col = tx + 16 * c;
+      float v = col == r ? 1.0f : 0.0f;
+      if (part == 0) {
+        v = a[r * lda + col];
+        v = col >= r ? v : 0.0f;
+      }
+      Z[i][c >> 1][c & 1] = v;
     }
   }
-#pragma unroll 1
-  for (int jb = 0; jb < 16; ++jb) {
-    // columns left of the group are finished (A part) / still zero right of it (Y part)
-    const bool active = ty >= jb && (part == 0 ? tx >= jb : tx <= jb);
-    if (part == 0 && ty == jb && tx == jb) {
-      float R[8][8], W[8][8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float s = Z[k][k >> 1][k & 1];
-#pragma unroll
-        for (int i = 0; i < k; ++i) s = __builtin_fmaf(-R[i][k], R[i][k], s);
-        if (!(s > 0.0f)) atomicMin(info, index_base + 8 * jb + k + 1);
-        float inv = __builtin_amdgcn_rsqf(s);
-        inv = inv * (1.5f - 0.5f * s * inv * inv);  // one Newton step: full float32 accuracy
-        R[k][k] = s * inv;
-#pragma unroll
-        for (int c = k + 1; c < 8; ++c) {
-          float t = Z[k][c >> 1][c & 1];
-#pragma unroll
-          for (int i = 0; i < k; ++i) t = __builtin_fmaf(-R[i][k], R[i][c], t);
-          R[k][c] = t * inv;
-        }
-        // row k of L^-1: W[k][k] = 1 / L[k][k], W[k][i] = -W[k][k] * sum_{m = i .. k-1} L[k][m] W[m][i], L[k][m] = R[m][k]
-        W[k][k] = inv;
-#pragma unroll
-        for (int i = 0; i < k; ++i) {
-          float t = 0.0f;
-#pragma unroll
-          for (int m = i; m < k; ++m) t = __builtin_fmaf(R[m][k], W[m][i], t);
-          W[k][i] = -inv * t;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wmat[k][i] = i <= k ? W[k][i] : 0.0f;
-    }
-    __syncthreads();
-    if (active && ty == jb) {
-      // final rows of the group: rows <- W x rows, from the last row up (row k only needs rows <= k)
-#pragma unroll
-      for (int k = 7; k >= 0; --k) {
-        f32x2 acc[4];
-        const float wkk = wmat[k][k];
-#pragma unroll
-        for (int h = 0; h < 4; ++h) acc[h] = Z[k][h] * f32x2{wkk, wkk};
-#pragma unroll
-        for (int i = 0; i < k; ++i) {
-          const float w = wmat[k][i];
-#pragma unroll
-          for (int h = 0; h < 4; ++h) acc[h] = __builtin_elementwise_fma(f32x2{w, w}, Z[i][h], acc[h]);
-        }
-#pragma unroll
-        for (int h = 0; h < 4; ++h) Z[k][h] = acc[h];
-        float4* dst = reinterpret_cast<float4*>(&rows[k][part][8 * tx]);
-        dst[0] = make_float4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
-        dst[1] = make_float4(acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
-      }
-    }
-    __syncthreads();
-    if (active && ty > jb) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float4 m0 = *reinterpret_cast<const float4*>(&rows[k][0][8 * ty]);
-        const float4 m1 = *reinterpret_cast<const float4*>(&rows[k][0][8 * ty + 4]);
-        const float4 c0 = *reinterpret_cast<const float4*>(&rows[k][part][8 * tx]);
-        const float4 c1 = *reinterpret_cast<const float4*>(&rows[k][part][8 * tx + 4]);
-        const float m[8] = {-m0.x, -m0.y, -m0.z, -m0.w, -m1.x, -m1.y, -m1.z, -m1.w};
-        const f32x2 rc[4] = {{c0.x, c0.y}, {c0.z, c0.w}, {c1.x, c1.y}, {c1.z, c1.w}};
-#pragma unroll
-        for (int ii = 0; ii < 8; ++ii) {
-          const f32x2 mm = {m[ii], m[ii]};
-#pragma unroll
-          for (int h = 0; h < 4; ++h) Z[ii][h] = __builtin_elementwise_fma(mm, rc[h], Z[ii][h]);
-        }
-      }
-    }
-    // no barrier here: the next group's W is written after this group's second barrier and read after the next
-    // group's first; `rows` is rewritten after the next group's first barrier, which every reader above has passed
-  }
+  static_for<8>([&](auto i0) { panel_groups<decltype(i0)::value>(Z, lds, info, index_base, tid); });
   if (part == 0) {  // R11 in place (strict lower part zero)
 #pragma unroll
-    for (int ii = 0; ii < 8; ++ii) {
-      const int r = 8 * ty + ii;
-      float v[8];
+    for (int i = 0; i < 8; ++i) {
+      const int r = ty + 16 * i;
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) v[cc] = 8 * tx + cc >= r ? Z[ii][cc >> 1][cc & 1] : 0.0f;
-      *reinterpret_cast<float4*>(a + r * lda + 8 * tx) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(a + r * lda + 8 * tx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      for (int c = 0; c < 8; ++c) {
+        const int col = tx + 16 * c;
+        a[r * lda + col] = col >= r ? Z[i][c >> 1][c & 1] : 0.0f;
+      }
     }
-  } else if (tx <= ty) {  // X11 = Y^T into the inverse matrix (upper; its lower part stays zero)
+  } else {  // X11 = Y^T into the inverse matrix (upper; its lower part stays zero)
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      const int c = 8 * tx + cc;  // row of X
-      float v[8];
+    for (int i = 0; i < 8; ++i) {
+      const int r = ty + 16 * i;
 #pragma unroll
-      for (int ii = 0; ii < 8; ++ii) v[ii] = 8 * ty + ii >= c ? Z[ii][cc >> 1][cc & 1] : 0.0f;
-      *reinterpret_cast<float4*>(x + c * ldx + 8 * ty) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(x + c * ldx + 8 * ty + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      for (int c = 0; c < 8; ++c) {
+        const int col = tx + 16 * c;  // row of X
+        if (r >= col) x[col * ldx + r] = Z[i][c >> 1][c & 1];
+      }
     }
   }
 }
