@@ -1035,59 +1035,202 @@ __global__ __launch_bounds__(kPanelThreads) void panel_factor_kernel(float* a, i
 // Two adjacent diagonal blocks in ONE launch: the recursion's lowest internal node (leaf, R12, trailing update,
 // leaf, X12) run by one workgroup.  Launched separately, its six kernels are a few microseconds of work each and
 // spend most of their time waiting to be dispatched next to other streams' kernels; here the workgroup stays
-// resident.  The four 128^3 products run as 64 x 64 tiles, two at a time (one per half of the workgroup); the
-// halves are kept on the same barrier count (gemm_tile's extra_barriers).
+// resident.
+//
+// The four 128^3 products run on the float16 matrix pipe with two terms per operand, like the large products above,
+// but with everything inside the workgroup: each thread fetches its share of both operands (64 values each), the
+// largest magnitudes per column (k-major operand) or row are gathered with LDS atomics, the scaled values are split
+// into the four K-step images of the operand in LDS (the layout of split_planes_kernel), and the 8 waves multiply:
+// wave (wr, wc, h) takes the fragments i = 2 h, 2 h + 1 of the 64 x 64 quarter (wr, wc).  The triangular operands
+// are multiplied as full blocks (their zeros cost 2 us of matrix time per node, the bookkeeping would cost more).
+// The images overlay the leaf's LDS: the two never live at the same time.
 // ---------------------------------------------------------------------------------------------
-constexpr int kPairTile = 64;
-constexpr int kPairGemmFloats = 2 * 2 * GemmStep<kPairTile>::value * (kPairTile + 4);  // one half's double buffer
+constexpr int kPairImagesBytes = 4 * kImageBytes;  // one 128 x 128 operand: four K steps of 32
+constexpr size_t kPairLdsBytes = 2 * kPairImagesBytes + 2 * kNb * sizeof(unsigned);  // images of A and B, magnitudes
+static_assert(sizeof(PanelLds) <= 2 * kPairImagesBytes, "the leaf's LDS must fit under the images");
+static_assert(kNb == 128 && kPanelThreads == 512, "the pair products are written for 128-blocks and 512 threads");
 
-constexpr size_t kPairPanelBytes = (sizeof(PanelLds) + 255) / 256 * 256;
-constexpr size_t kPairLdsBytes = kPairPanelBytes + 2 * kPairGemmFloats * sizeof(float);
-
-template <bool A_KMAJOR>
-__device__ __forceinline__ void pair_product(GemmParams g, float* lds) {
-  constexpr int T = kPairTile, kGK = GemmStep<T>::value;
-  g.tiles_m = (g.M + T - 1) / T;
-  g.tiles_n = (g.N + T - 1) / T;
-  const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
-  float* my_lds = lds + half * kPairGemmFloats;
-  // the tiles in a fixed order (skipping those below the diagonal of an upper-only product), two per round
-  int list[4], count = 0;
-  for (int t = 0; t < g.tiles_m * g.tiles_n; ++t) {
-    const int tm = t % g.tiles_m, tn = t / g.tiles_m;
-    if (!(g.upper_only && tn < tm)) list[count++] = t;
+// A thread's 64 values of a 128 x 128 operand.  k-major (src[k][c]): columns 4 q .. 4 q + 3 of the 8 k-values of chunk
+// tid / 32; row-major (src[r][k]): k = 32 (tid / 128) + 4 (u % 8) .. + 3 of the rows at image positions 16 it + u / 8.
+template <bool KMAJOR>
+__device__ __forceinline__ void pair_fetch(const float* src, int64_t ld, int tid, float4 (&v)[8]) {
+  if constexpr (KMAJOR) {
+    const int q = tid & 31, k0 = 8 * (tid >> 5);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(src + (k0 + j) * ld + 4 * q);
+  } else {
+    const int u = tid & 127, ks = tid >> 7;
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      v[it] = *reinterpret_cast<const float4*>(src + split_row_of(16 * it + (u >> 3)) * ld + 32 * ks + 4 * (u & 7));
   }
-  auto steps_of = [&](int t, int& k_begin) {
-    const int m0 = (t % g.tiles_m) * T, n0 = (t / g.tiles_m) * T;
-    int k_end = g.K;
-    k_begin = 0;
-    if (g.k_above_m) k_begin = max(k_begin, m0 / kGK * kGK);
-    if (g.k_below_m) k_end = min(k_end, m0 + T);
-    if (g.k_below_n) k_end = min(k_end, n0 + T);
-    return k_end > k_begin ? (k_end - k_begin) / kGK : 0;
-  };
-  for (int r = 0; r < count; r += 2) {
-    int kb0, kb1 = 0;
-    const int nk0 = steps_of(list[r], kb0);
-    const int nk1 = r + 1 < count ? steps_of(list[r + 1], kb1) : -1;  // -1: the second half has no tile in this pass
-    const int most = max(nk0, nk1);
-    const int mine = half == 0 ? list[r] : (r + 1 < count ? list[r + 1] : -1);
-    if (mine >= 0) {
-      const int m0 = (mine % g.tiles_m) * T, n0 = (mine / g.tiles_m) * T;
-      const int nk = half == 0 ? nk0 : nk1, kb = half == 0 ? kb0 : kb1;
-      gemm_tile<A_KMAJOR, true, T>(g, my_lds, m0, n0, kb, nk, tid, most - nk);
-    } else {
-      for (int i = 0; i < 1 + most; ++i) __syncthreads();
+}
+
+__device__ __forceinline__ unsigned magnitude_bits(float x) { return __builtin_bit_cast(unsigned, x) & 0x7fffffffu; }
+
+// amax[c] (k-major: column c; row-major: row c) = largest magnitude as a bit pattern; amax starts zeroed
+template <bool KMAJOR>
+__device__ __forceinline__ void pair_magnitudes(const float4 (&v)[8], int tid, unsigned* amax) {
+  if constexpr (KMAJOR) {
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      m[0] = max(m[0], magnitude_bits(v[j].x));
+      m[1] = max(m[1], magnitude_bits(v[j].y));
+      m[2] = max(m[2], magnitude_bits(v[j].z));
+      m[3] = max(m[3], magnitude_bits(v[j].w));
+    }
+    const int q = tid & 31;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicMax(&amax[4 * q + e], m[e]);
+  } else {
+    const int u = tid & 127;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      unsigned m = max(max(magnitude_bits(v[it].x), magnitude_bits(v[it].y)),
+                       max(magnitude_bits(v[it].z), magnitude_bits(v[it].w)));
+      m = max(m, static_cast<unsigned>(__shfl_xor(static_cast<int>(m), 1)));
+      m = max(m, static_cast<unsigned>(__shfl_xor(static_cast<int>(m), 2)));
+      m = max(m, static_cast<unsigned>(__shfl_xor(static_cast<int>(m), 4)));
+      if ((u & 7) == 0) atomicMax(&amax[split_row_of(16 * it + (u >> 3))], m);
     }
   }
-  __syncthreads();  // the product is in memory for every thread of the workgroup
+}
+
+// the values, scaled into float16's range, as two terms in the operand's four images
+template <bool KMAJOR>
+__device__ __forceinline__ void pair_split(const float4 (&v)[8], int tid, const unsigned* amax, unsigned char* images) {
+  float unused;
+  if constexpr (KMAJOR) {
+    const int q = tid & 31, kc = (tid >> 5) & 3, ks = tid >> 7;
+    float sc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) half_scale_of(amax[4 * q + e], sc[e], unused);
+    unsigned char* at = images + ks * kImageBytes + kc * kSplitChunkBytes + (((q & 15) ^ kc) + 64 * (q >> 4)) * 16;
+    {
+      const float x[8] = {v[0].x * sc[0], v[1].x * sc[0], v[2].x * sc[0], v[3].x * sc[0],
+                          v[4].x * sc[0], v[5].x * sc[0], v[6].x * sc[0], v[7].x * sc[0]};
+      split_store<2>(x, at);
+    }
+    {
+      const float x[8] = {v[0].y * sc[1], v[1].y * sc[1], v[2].y * sc[1], v[3].y * sc[1],
+                          v[4].y * sc[1], v[5].y * sc[1], v[6].y * sc[1], v[7].y * sc[1]};
+      split_store<2>(x, at + 16 * 16);
+    }
+    {
+      const float x[8] = {v[0].z * sc[2], v[1].z * sc[2], v[2].z * sc[2], v[3].z * sc[2],
+                          v[4].z * sc[2], v[5].z * sc[2], v[6].z * sc[2], v[7].z * sc[2]};
+      split_store<2>(x, at + 32 * 16);
+    }
+    {
+      const float x[8] = {v[0].w * sc[3], v[1].w * sc[3], v[2].w * sc[3], v[3].w * sc[3],
+                          v[4].w * sc[3], v[5].w * sc[3], v[6].w * sc[3], v[7].w * sc[3]};
+      split_store<2>(x, at + 48 * 16);
+    }
+  } else {
+    const int u = tid & 127, ks = tid >> 7, ck = (u & 7) >> 1;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int srow = 16 * it + (u >> 3);
+      float scale;
+      half_scale_of(amax[split_row_of(srow)], scale, unused);
+      uint2 h, l;
+      split_pair(f32x2{v[it].x * scale, v[it].y * scale}, h.x, l.x);
+      split_pair(f32x2{v[it].z * scale, v[it].w * scale}, h.y, l.y);
+      unsigned char* at = images + ks * kImageBytes + ck * kSplitChunkBytes + (srow ^ ck) * 16 + (u & 1) * 8;
+      *reinterpret_cast<uint2*>(at) = h;
+      *reinterpret_cast<uint2*>(at + kSplitPlaneBytes) = l;
+    }
+  }
+}
+
+// C = alpha (A B) + beta C from the images; lane (g, j) of wave (wr, wc, h) ends up with
+// C[64 wr + 16 g + 4 r + 2 h + i][64 wc + 4 j + n], i < 2, n < 4, r < 4
+__device__ __forceinline__ void pair_multiply(const unsigned char* img_a, const unsigned char* img_b, const unsigned* amax_a,
+                                              const unsigned* amax_b, float alpha, float beta, float* C, int64_t ldc, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = (wave >> 1) & 1, hh = wave & 1;
+  const int g = lane >> 4, j = lane & 15;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const unsigned char* fa = img_a + g * kSplitChunkBytes + (64 * wr + (j ^ g)) * 16 + 2 * hh * 256;
+  const unsigned char* fb = img_b + g * kSplitChunkBytes + (64 * wc + (j ^ g)) * 16;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    u32x4 a[2][2], b[2][4];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[pl][i] = *reinterpret_cast<const u32x4*>(fa + ks * kImageBytes + pl * kSplitPlaneBytes + i * 256);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        b[pl][n] = *reinterpret_cast<const u32x4*>(fb + ks * kImageBytes + pl * kSplitPlaneBytes + n * 256);
+    }
+    constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};  // l h', h l', h h': smallest terms first
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[pa[t]][i]),
+                                                             __builtin_bit_cast(f16x8, b[pb[t]][n]), acc[i][n], 0, 0, 0);
+  }
+  float unused, back_b[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) half_scale_of(amax_b[64 * wc + 4 * j + e], unused, back_b[e]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 64 * wr + 16 * g + 4 * r + 2 * hh + i, col = 64 * wc + 4 * j;
+      float back_a;
+      half_scale_of(amax_a[row], unused, back_a);
+      float4 out = make_float4(alpha * ((acc[i][0][r] * back_a) * back_b[0]), alpha * ((acc[i][1][r] * back_a) * back_b[1]),
+                               alpha * ((acc[i][2][r] * back_a) * back_b[2]), alpha * ((acc[i][3][r] * back_a) * back_b[3]));
+      float* c = C + row * ldc + col;
+      if (beta != 0.0f) {
+        const float4 old = *reinterpret_cast<const float4*>(c);
+        out = make_float4(beta * old.x + out.x, beta * old.y + out.y, beta * old.z + out.z, beta * old.w + out.w);
+      }
+      *reinterpret_cast<float4*>(c) = out;
+    }
+}
+
+// One 128^3 product of the node.  B is k-major (B[k][n]); A is k-major (A[k][m]) or row-major; SAME: A is B, k-major
+// (R12^T R12).  C may be B itself: every thread has B's values in registers before the first barrier.  On return the
+// result is visible to the whole workgroup and the LDS is free.
+template <bool A_KMAJOR, bool SAME>
+__device__ __forceinline__ void pair_product(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                                             float alpha, float beta, unsigned char* smem) {
+  const int tid = threadIdx.x;
+  unsigned char* img_a = smem;
+  unsigned char* img_b = smem + kPairImagesBytes;
+  unsigned* amax_a = reinterpret_cast<unsigned*>(smem + 2 * kPairImagesBytes);
+  unsigned* amax_b = amax_a + kNb;
+  float4 va[8], vb[8];
+  pair_fetch<true>(B, ldb, tid, vb);
+  if constexpr (!SAME) pair_fetch<A_KMAJOR>(A, lda, tid, va);
+  if (tid < 2 * kNb) amax_a[tid] = 0u;
+  __syncthreads();
+  pair_magnitudes<true>(vb, tid, amax_b);
+  if constexpr (!SAME) pair_magnitudes<A_KMAJOR>(va, tid, amax_a);
+  __syncthreads();
+  pair_split<true>(vb, tid, amax_b, img_b);
+  if constexpr (!SAME) pair_split<A_KMAJOR>(va, tid, amax_a, img_a);
+  __syncthreads();
+  pair_multiply(SAME ? img_b : img_a, img_b, SAME ? amax_b : amax_a, amax_b, alpha, beta, C, ldc, tid);
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(kPanelThreads) void pair_factor_kernel(float* A, float* X, float* Tm, int64_t np,
                                                                      int32_t first_block, int32_t* info) {
-  extern __shared__ __align__(16) unsigned char pair_smem[];  // kPairLdsBytes: [PanelLds | two halves' tile buffers]
+  extern __shared__ __align__(16) unsigned char pair_smem[];  // kPairLdsBytes: the leaf's PanelLds, then the products' images
   PanelLds& panel_lds = *reinterpret_cast<PanelLds*>(pair_smem);
-  float* gemm_lds = reinterpret_cast<float*>(pair_smem + kPairPanelBytes);
   const int64_t o1 = static_cast<int64_t>(first_block) * kNb, o2 = o1 + kNb;
   float* a11 = A + o1 * np + o1;
   float* a12 = A + o1 * np + o2;
@@ -1097,36 +1240,12 @@ __global__ __launch_bounds__(kPanelThreads) void pair_factor_kernel(float* A, fl
   float* x22 = X + o2 * np + o2;
   panel_factor(a11, np, x11, np, info, static_cast<int32_t>(o1), panel_lds);
   __syncthreads();
-  GemmParams g{};
-  g.M = g.N = g.K = kNb;
-  g.vec_a = g.vec_b = 1;
-  {  // R12 = X11^T A12 -> Tm, then copied over A12
-    g.A = x11, g.lda = np, g.B = a12, g.ldb = np, g.C = Tm, g.ldc = kNb;
-    g.alpha = 1.0f, g.beta = 0.0f, g.upper_only = 0, g.k_above_m = 0, g.k_below_m = 1, g.k_below_n = 0;
-    pair_product<true>(g, gemm_lds);
-    for (int e = threadIdx.x; e < kNb * kNb / 4; e += kPanelThreads) {
-      const int r = e / (kNb / 4), c4 = (e % (kNb / 4)) * 4;
-      *reinterpret_cast<float4*>(a12 + r * np + c4) = *reinterpret_cast<const float4*>(Tm + r * kNb + c4);
-    }
-    __syncthreads();
-  }
-  {  // A22 -= R12^T R12 (upper triangle)
-    g.A = a12, g.lda = np, g.B = a12, g.ldb = np, g.C = a22, g.ldc = np;
-    g.alpha = -1.0f, g.beta = 1.0f, g.upper_only = 1, g.k_above_m = 0, g.k_below_m = 0, g.k_below_n = 0;
-    pair_product<true>(g, gemm_lds);
-  }
+  pair_product<true, false>(x11, np, a12, np, a12, np, 1.0f, 0.0f, pair_smem);   // R12 = X11^T A12, over A12
+  pair_product<true, true>(a12, np, a12, np, a22, np, -1.0f, 1.0f, pair_smem);   // A22 -= R12^T R12
   panel_factor(a22, np, x22, np, info, static_cast<int32_t>(o2), panel_lds);
   __syncthreads();
-  {  // Tm = R12 X22 (X22 upper: k <= n)
-    g.A = a12, g.lda = np, g.B = x22, g.ldb = np, g.C = Tm, g.ldc = kNb;
-    g.alpha = 1.0f, g.beta = 0.0f, g.upper_only = 0, g.k_above_m = 0, g.k_below_m = 0, g.k_below_n = 1;
-    pair_product<false>(g, gemm_lds);
-  }
-  {  // X12 = -X11 Tm (X11 upper: k >= m)
-    g.A = x11, g.lda = np, g.B = Tm, g.ldb = kNb, g.C = x12, g.ldc = np;
-    g.alpha = -1.0f, g.beta = 0.0f, g.upper_only = 0, g.k_above_m = 1, g.k_below_m = 0, g.k_below_n = 0;
-    pair_product<false>(g, gemm_lds);
-  }
+  pair_product<false, false>(a12, np, x22, np, Tm, kNb, 1.0f, 0.0f, pair_smem);  // Tm = R12 X22
+  pair_product<false, false>(x11, np, Tm, kNb, x12, np, -1.0f, 0.0f, pair_smem); // X12 = -X11 Tm
 }
 
 // dst[i][j] = S[n-1-i][n-1-j] for i, j < n and the identity on the padding up to np, where
