@@ -875,98 +875,106 @@ static int launch_gemm(const GemmParams& pin, bool a_kmajor, hipStream_t s, int 
 constexpr int kPanelThreads = 512;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Column t + 16 e of a part (t < 16, e < 8) is at position 8 t + e of a pivot row as it stands, so that a thread's 8
+// elements of a row are two 16-byte accesses.  The final rows are kept as [part][t][pivot k][e], 72 floats per t (64
+// and a pad that spreads the column writers over the banks): what thread column tx needs of all 8 pivot rows -- and,
+// read at t = ty in the A part, the entries of thread rows ty + 16 i in the 8 pivot columns -- is one contiguous run.
+constexpr int kPanelFinalStride = 72;
 struct PanelLds {
-  float raw[8][2][kNb];   // the group's pivot rows as they stand: [row][A part | Y part][column]
-  float rows[8][2][kNb];  // ... and their final values
+  float raw[8][2][kNb];                      // the group's pivot rows as they stand: [row][A part | Y part][position]
+  float fin[2][16][kPanelFinalStride];       // ... and their final values
 };
-
-// The 8 x 8 diagonal block D = R^T R of a pivot group (upper triangle of `d` used): R (upper) and 1 / R[k][k].
-__device__ __forceinline__ void factor_8x8(const float (&d)[8][8], float (&R)[8][8], float (&inv)[8], int32_t* info,
-                                           int32_t first_index, bool report) {
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float s = d[k][k];
-#pragma unroll
-    for (int i = 0; i < k; ++i) s = __builtin_fmaf(-R[i][k], R[i][k], s);
-    if (report && !(s > 0.0f)) atomicMin(info, first_index + k + 1);
-    float r = __builtin_amdgcn_rsqf(s);
-    r = r * (1.5f - 0.5f * s * r * r);  // one Newton step: full float32 accuracy
-    inv[k] = r;
-    R[k][k] = s * r;
-#pragma unroll
-    for (int c = k + 1; c < 8; ++c) {
-      float t = d[k][c];
-#pragma unroll
-      for (int i = 0; i < k; ++i) t = __builtin_fmaf(-R[i][k], R[i][c], t);
-      R[k][c] = t * r;
-    }
-  }
-}
 
 // The two pivot groups whose rows lie in row band I0 (rows 16 I0 .. 16 I0 + 15).  Thread (part, ty, tx) owns the
 // elements (ty + 16 i, tx + 16 c), i, c < 8, of its part: rows and columns are dealt out cyclically, so that what is
 // left to update shrinks for every thread alike as the pivots advance -- the row bands above I0 and, in the A part,
 // the column bands left of it (in the Y part: right of it) are skipped by the whole workgroup, at compile time.
+// `bad`: smallest 1-based global index of a non-positive pivot seen so far.
 template <int I0>
-__device__ __forceinline__ void panel_groups(f32x2 (&Z)[8][4], PanelLds& lds, int32_t* info, int32_t index_base, int tid) {
+__device__ __forceinline__ void panel_groups(f32x2 (&Z)[8][4], PanelLds& lds, int32_t& bad, int32_t index_base, int tid) {
   const int tx = tid & 15, ty = (tid >> 4) & 15, part = tid >> 8;
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     const int o = 8 * half, p0 = 16 * I0 + o;  // pivots p0 .. p0 + 7: thread rows / columns o .. o + 7 of band I0
     // 1. the pivot rows as they stand
     if (ty >= o && ty < o + 8) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) lds.raw[ty - o][part][tx + 16 * c] = Z[I0][c >> 1][c & 1];
+      f32x4* at = reinterpret_cast<f32x4*>(&lds.raw[ty - o][part][8 * tx]);
+      at[0] = f32x4{Z[I0][0][0], Z[I0][0][1], Z[I0][1][0], Z[I0][1][1]};
+      at[1] = f32x4{Z[I0][2][0], Z[I0][2][1], Z[I0][3][0], Z[I0][3][1]};
     }
     __syncthreads();
-    // 2. waves 0-3 (one per SIMD), one column of [A | Y] per thread: the factor R of the diagonal block, computed by
-    //    every thread for itself (the same chain of dependent operations whether one thread runs it or 256), then the
-    //    column's entries of the final rows R^-T x rows
+    // 2. waves 0-3 (one per SIMD), one column of [A | Y] per thread: Cholesky elimination on the 8 x 8 diagonal block
+    //    D = R^T R with the thread's column x of the 8 rows carried along as a ninth column, which leaves R^-T x there
+    //    (the column's entries of the final rows).  Every thread factors D for itself: the same chain of dependent
+    //    operations whether one thread runs it or 256.  Each pivot's updates are applied at once to everything after
+    //    it (independent operations), and nothing branches.
     if (tid < 256) {
-      float d[8][8], R[8][8], inv[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int c = k; c < 8; ++c) d[k][c] = lds.raw[k][0][p0 + c];
-      factor_8x8(d, R, inv, info, index_base + p0, tid == 0);
-      // the column's entries of the final rows: R^T f = raw by forward substitution (rows of the A part become R,
-      // rows of the Y part R^-T so far)
-      const int pj = tid >> 7, col = tid & 127;
-      float f[8];
+      const int pj = tid >> 7, pos = tid & 127;
+      float d[8][8], x[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        float t = lds.raw[k][pj][col];
 #pragma unroll
-        for (int i = 0; i < k; ++i) t = __builtin_fmaf(-R[i][k], f[i], t);
-        f[k] = t * inv[k];
-        lds.rows[k][pj][col] = f[k];
+        for (int c = k; c < 8; ++c) d[k][c] = lds.raw[k][0][8 * (o + c) + I0];
+        x[k] = lds.raw[k][pj][pos];
+      }
+      float* out = &lds.fin[pj][pos >> 3][pos & 7];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float s = d[k][k];
+        bad = min(bad, s > 0.0f ? INT32_MAX : index_base + p0 + k + 1);
+        float r = __builtin_amdgcn_rsqf(s);
+        r = r * (1.5f - 0.5f * s * r * r);  // one Newton step: full float32 accuracy
+#pragma unroll
+        for (int c = k + 1; c < 8; ++c) d[k][c] *= r;  // row k of R
+        x[k] *= r;
+        out[8 * k] = x[k];
+#pragma unroll
+        for (int i = k + 1; i < 8; ++i) {
+#pragma unroll
+          for (int c = i; c < 8; ++c) d[i][c] = __builtin_fmaf(-d[k][i], d[k][c], d[i][c]);
+          x[i] = __builtin_fmaf(-d[k][i], x[k], x[i]);
+        }
       }
     }
     __syncthreads();
     // 3. the pivot rows take their final values; every row below subtracts (its entries in the pivot columns) x
     //    (final rows).  In band I0 only the rows below the group take part (none for the band's second group).
     if (ty >= o && ty < o + 8) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) Z[I0][c >> 1][c & 1] = lds.rows[ty - o][part][tx + 16 * c];
+      const f32x4* at = reinterpret_cast<const f32x4*>(&lds.fin[part][tx][8 * (ty - o)]);
+      const f32x4 v0 = at[0], v1 = at[1];
+      Z[I0][0] = f32x2{v0[0], v0[1]};
+      Z[I0][1] = f32x2{v0[2], v0[3]};
+      Z[I0][2] = f32x2{v1[0], v1[1]};
+      Z[I0][3] = f32x2{v1[2], v1[3]};
     }
-    // column bands that can be non-zero and are still needed: A part I0 .. 7, Y part 0 .. I0 (a pair of bands per h)
+    // column bands that can be non-zero and are still needed: A part I0 .. 7, Y part 0 .. I0 (a pair of bands per h).
+    // Everything the update needs is requested from LDS before its first multiply-add.
     auto update = [&](auto lo_const, auto hi_const) __attribute__((always_inline)) {
       constexpr int lo = decltype(lo_const)::value, hi = decltype(hi_const)::value;
       const bool band_live = ty >= o + 8;  // rows of band I0 below the group
+      const f32x4* mrow = reinterpret_cast<const f32x4*>(&lds.fin[0][ty][0]);     // [k][i / 4]: rows ty + 16 i
+      const f32x4* crow = reinterpret_cast<const f32x4*>(&lds.fin[part][tx][0]);  // [k][c / 4]: columns tx + 16 c
+      f32x4 mult[8][2], rc[8][2];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        f32x2 rc[4];
+        if constexpr (I0 < 4) mult[k][0] = mrow[2 * k];
+        mult[k][1] = mrow[2 * k + 1];
+        if constexpr (lo < 2) rc[k][0] = crow[2 * k];
+        if constexpr (hi > 2) rc[k][1] = crow[2 * k + 1];
+      }
 #pragma unroll
-        for (int h = lo; h < hi; ++h)
-          rc[h] = f32x2{lds.rows[k][part][tx + 16 * (2 * h)], lds.rows[k][part][tx + 16 * (2 * h + 1)]};
+      for (int k = 0; k < 8; ++k) {
         static_for<8>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
           if constexpr (i >= I0) {
             if (i > I0 || band_live) {
-              const float m = -lds.rows[k][0][ty + 16 * i];
+              const float m = -mult[k][i >> 2][i & 3];
               const f32x2 mm = {m, m};
 #pragma unroll
-              for (int h = lo; h < hi; ++h) Z[i][h] = __builtin_elementwise_fma(mm, rc[h], Z[i][h]);
+              for (int h = lo; h < hi; ++h) {
+                const f32x2 pair = {rc[k][h >> 1][2 * (h & 1)], rc[k][h >> 1][2 * (h & 1) + 1]};
+                Z[i][h] = __builtin_elementwise_fma(mm, pair, Z[i][h]);
+              }
             }
           }
         });
@@ -978,7 +986,7 @@ __device__ __forceinline__ void panel_groups(f32x2 (&Z)[8][4], PanelLds& lds, in
       update(std::integral_constant<int, 0>{}, std::integral_constant<int, I0 / 2 + 1>{});
     }
     // no barrier here: `raw` is rewritten before the next group's first barrier and was last read before this
-    // group's second; `rows` is rewritten after the next group's first barrier, which every reader above has passed
+    // group's second; `fin` is rewritten after the next group's first barrier, which every reader above has passed
   }
 }
 
@@ -1001,7 +1009,9 @@ __device__ __forceinline__ void panel_factor(float* a, int64_t lda, float* x, in
       Z[i][c >> 1][c & 1] = v;
     }
   }
-  static_for<8>([&](auto i0) { panel_groups<decltype(i0)::value>(Z, lds, info, index_base, tid); });
+  int32_t bad = INT32_MAX;
+  static_for<8>([&](auto i0) { panel_groups<decltype(i0)::value>(Z, lds, bad, index_base, tid); });
+  if (tid == 0 && bad != INT32_MAX) atomicMin(info, bad);
   if (part == 0) {  // R11 in place (strict lower part zero)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
