@@ -102,14 +102,11 @@ def stage_config():
         kernel_gptq=QuantGptqConfig(damp_percentage=0.01, block_size=128, num_inv_tries=250, hessian_block_size=512))
 
 
-def quantize_layer(weights, caches, config, syrk_events=None, streams: int = 1, world: int = 1, rank: int = 0):
-    """The hot path for one layer through the weight stage of the package (the reference's
-    app/llm/quant/weight.py:24-105): range search, then GPTQ fed by the cached inputs, for the 7 linears.  Returns the
-    modules holding the dequantized weights (kept so nothing is optimised away)."""
+def layer_entries(weights, caches):
+    """The 7 linears of a layer as the weight stage takes them: (entries, layer cache)."""
     import torch.nn as nn
 
-    from deepcompressor_amd import _lib
-    from deepcompressor_amd.app import LinearEntry, quantize_layer_weights
+    from deepcompressor_amd.app import LinearEntry
     from deepcompressor_amd.data.cache import IOTensorsCache, TensorsCache
 
     entries, layer_cache = [], {}
@@ -119,6 +116,29 @@ def quantize_layer(weights, caches, config, syrk_events=None, streams: int = 1, 
         module.weight = nn.Parameter(w, requires_grad=False)  # the stage replaces .data, `weights` keeps the original
         entries.append(LinearEntry(key=name, name=f"layer.{name}", module=module))
         layer_cache[f"layer.{name}"] = IOTensorsCache(inputs=TensorsCache(caches[key]))
+    return entries, layer_cache
+
+
+def caches_of_another_layer(caches):
+    """The same activations as the cached inputs of ANOTHER layer: new tensor objects over the same memory.  The stage
+    tells caches apart by the identity of their tensors, as it must between the layers of a model; with these, two
+    consecutive steps look to it like two consecutive layers, and nothing computed for one is taken for the other."""
+    from deepcompressor_amd.data.cache import TensorCache
+
+    return {key: TensorCache([t.view(t.shape) for t in c.data], channels_dim=c.channels_dim, reshape=c.reshape,
+                             num_cached=c.num_cached, num_total=c.num_total, num_samples=c.num_samples,
+                             orig_device=c.orig_device) for key, c in caches.items()}
+
+
+def quantize_layer(weights, caches, config, syrk_events=None, streams: int = 1, world: int = 1, rank: int = 0,
+                   next_caches=None):
+    """The hot path for one layer through the weight stage of the package (the reference's
+    app/llm/quant/weight.py:24-105): range search, then GPTQ fed by the cached inputs, for the 7 linears.  Returns the
+    modules holding the dequantized weights (kept so nothing is optimised away).  ``next_caches``: the cached inputs of
+    the layer the next call is for; its Hessians are queued beside this layer's pipelines (the stage's ``prefetch``)."""
+    from deepcompressor_amd.app import prepare_layer_hessians, quantize_layer_weights
+
+    entries, layer_cache = layer_entries(weights, caches)
 
     def hessian_hook(channels):
         if syrk_events is None:
@@ -127,8 +147,12 @@ def quantize_layer(weights, caches, config, syrk_events=None, streams: int = 1, 
         syrk_events.append((e0, e1, channels))
         return e0, e1  # recorded by the library right around this Hessian's SYRK launches, on their stream
 
+    prefetch = None
+    if next_caches is not None:
+        next_entries, next_cache = layer_entries(weights, next_caches)
+        prefetch = lambda: prepare_layer_hessians(next_entries, next_cache, hessian_hook=hessian_hook)  # noqa: E731
     quantize_layer_weights(entries, config, {}, layer_cache=layer_cache, streams=streams, hessian_hook=hessian_hook,
-                           world=world, rank=rank)
+                           world=world, rank=rank, prefetch=prefetch)
     return [e.module for e in entries]
 
 
@@ -490,6 +514,9 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip the stage rooflines and the other configs")
     ap.add_argument("--streams", type=int, default=4,
                     help="run the independent groups of linears of a layer concurrently on this many HIP streams")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="queue the next step's Hessians beside the current step's factorisations and sweeps (the "
+                         "stage's `prefetch`; measured: no gain, the step is bound by the kernels that fill the chip)")
     ap.add_argument("--shard", choices=("layers", "rows"), default="layers",
                     help="layers: every rank quantizes whole layers of its own (weak scaling); rows: one layer per "
                          "step for the whole job, tokens and output rows split over the ranks (strong scaling)")
@@ -541,14 +568,27 @@ def main() -> None:
     else:
         my_tokens, split = args.tokens, {}
         weights, caches = make_layer(device, args.tokens, seed=1234 + rank)
-    for _ in range(args.warmup):
-        quantize_layer(weights, caches, config, streams=args.streams, **split)
+    # --pipeline: steps are consecutive layers, and while a layer's factorisations and sweeps run, the next layer's
+    # Hessians are queued behind its own (the stage's `prefetch`).  Every step still computes its four Hessians itself,
+    # inside the loop it is counted in: the last step of either loop prepares nothing for a step after it, and the two
+    # sets of cache objects (the same activations) keep the stage from taking one step's Hessians for another's.
+    pipelined = args.pipeline and not rows_mode and args.streams > 1
+    cache_sets = [caches, caches_of_another_layer(caches)] if pipelined else [caches, caches]
+
+    def run_steps(n, events=None):
+        out = None
+        for i in range(n):
+            ahead = cache_sets[(i + 1) % 2] if pipelined and i + 1 < n else None
+            out = quantize_layer(weights, cache_sets[i % 2], config, events, streams=args.streams, next_caches=ahead,
+                                 **split)
+        return out
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     barrier_and_max(0.0, world, device)
     syrk_events: list = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        outputs = quantize_layer(weights, caches, config, syrk_events, streams=args.streams, **split)
+    outputs = run_steps(args.steps, syrk_events)
     torch.cuda.synchronize()
     elapsed = barrier_and_max(time.perf_counter() - t0, world, device)
     del outputs
@@ -605,7 +645,8 @@ def main() -> None:
                        "parallelism": (f"one layer over {world} ranks: tokens split (Hessians all-reduced), output "
                                        f"rows split (slabs all-gathered)" if rows_mode else
                                        f"independent layers x{world}"),
-                       "backend": args.backend if world > 1 else None, "streams_per_gpu": args.streams},
+                       "backend": args.backend if world > 1 else None, "streams_per_gpu": args.streams,
+                       "next_layer_hessians_prefetched": pipelined},
             # frac = matrix-core utilisation: the flops the kernel EXECUTES (upper-triangular 256-tiles only, about
             # half of 2 T C^2) over the dense bf16 peak; the algorithmic figure (2 T C^2 credited per launch) beside it
             "roofline": {"bound": "mfma", "achieved": executed, "peak": 2500.0, "unit": "TFLOP/s",

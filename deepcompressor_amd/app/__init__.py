@@ -3,8 +3,8 @@ files they leave behind.  Model loading, datasets, evaluation and the CLI of the
 not part of this package."""
 
 from .llm import (ActivationEntry, LinearEntry, LlmActivationQuantizer, LlmActivationQuantizerConfig, LlmQuantizer, LlmQuantizerConfig,
-                  LlmWeightQuantizer, LlmWeightQuantizerConfig, load_checkpoint, load_weight_checkpoint, quantize_layer_activations,
-                  quantize_layer_weights, save_checkpoint, save_weight_checkpoint)
+                  LlmWeightQuantizer, LlmWeightQuantizerConfig, load_checkpoint, load_weight_checkpoint, prepare_layer_hessians,
+                  quantize_layer_activations, quantize_layer_weights, save_checkpoint, save_weight_checkpoint)
 
 from .llm_stages import (LlmQuantConfig, quantize_llm_layer_activations, quantize_llm_layer_weights, reorder_llm_layer,
                          rotate_llm, smooth_llm_layer)
@@ -16,4 +16,4 @@ __all__ = ["LlmQuantConfig", "rotate_llm", "reorder_llm_layer", "smooth_llm_laye
            "LlmFeedForwardStruct", "LlmModelStruct", "LlmSelfAttentionStruct", "LlmTransformerBlockStruct",
            "LlmTransformerStruct", "ActivationEntry", "quantize_layer_activations", "LinearEntry", "LlmActivationQuantizer", "LlmActivationQuantizerConfig", "LlmQuantizer", "LlmQuantizerConfig",
            "LlmWeightQuantizer", "LlmWeightQuantizerConfig", "load_weight_checkpoint", "quantize_layer_weights",
-           "save_weight_checkpoint", "save_checkpoint", "load_checkpoint"]
+           "save_weight_checkpoint", "save_checkpoint", "load_checkpoint", "prepare_layer_hessians"]

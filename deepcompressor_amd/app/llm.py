@@ -176,7 +176,8 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
                            layer_cache: dict[str, IOTensorsCache] | None = None,
                            return_with_scale_state_dict: bool = False, develop_dtype: torch.dtype = torch.float32,
                            streams: int = 1, hessian_hook: tp.Callable[[int], tp.Any] | None = None,
-                           world: int = 1, rank: int = 0) -> dict[str, torch.Tensor | float | None]:
+                           world: int = 1, rank: int = 0,
+                           prefetch: tp.Callable[[], tp.Any] | None = None) -> dict[str, torch.Tensor | float | None]:
     """app/llm/quant/weight.py:24-105.  Pass 1 calibrates the range of every linear that has no entry in
     ``quantizer_state_dict`` yet (and stores it there); pass 2 reloads each range, quantizes the weight with the
     configured kernel (GPTQ when set, fed by the linear's cached inputs) and writes the dequantized weight back into
@@ -191,6 +192,13 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
     When no scale state dict is asked for, the weights of a group are quantized as one weight stacked along the output
     rows (``_quantize_stacked``: rows are independent given the Hessian, so the results are the same bit for bit, and
     one sweep stands where one per linear stood).
+
+    ``prefetch`` (no counterpart in the reference; ``streams`` > 1 only, ignored with ``world`` > 1): called once, on
+    the caller's stream, when this layer's own Hessians have been queued and before its pipelines are started.  Meant
+    for ``prepare_layer_hessians(next layer's entries, next layer's cache)``: the next layer's Hessians -- matrix-core
+    work that fills the chip and depends on nothing this layer produces (a layer's cached inputs are recorded before
+    the layer before it is quantized) -- then run beside this layer's factorisations and sweeps, which are chains of
+    small kernels, and the next call finds them prepared.
 
     ``world`` > 1 (no counterpart in the reference either): ONE layer split over the ``world`` processes of the default
     process group, one per GPU.  Every rank passes the same modules (full weights) and the cache of ITS share of the
@@ -208,13 +216,49 @@ def quantize_layer_weights(entries: tp.Sequence[LinearEntry], config: LlmWeightQ
     try:
         if streams > 1 and layer_cache and config.enabled_gptq and len(entries) > 1:
             return _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, layer_cache,
-                                                      return_with_scale_state_dict, develop_dtype, streams, hessian_hook)
+                                                      return_with_scale_state_dict, develop_dtype, streams, hessian_hook,
+                                                      prefetch)
+        if prefetch is not None:
+            prefetch()
         return _quantize_layer_weights(entries, config, quantizer_state_dict, layer_cache,
                                        return_with_scale_state_dict, develop_dtype)
     finally:
         # the GPTQ kernel memoises the Hessian (and its inverse factor) of the last activation cache together with a
-        # reference to that cache; a layer's caches must not outlive the layer
-        clear_hessian_cache()
+        # reference to that cache; a layer's caches must not outlive the layer (what `prefetch` prepared for the next
+        # layer lives until the end of that layer's call)
+        clear_hessian_cache(keep_ahead=prefetch is not None)
+
+
+def _groups_by_inputs(entries, layer_cache, device):
+    """The linears grouped by the cached inputs they share, the costliest pipeline first."""
+    from ..quantizer.kernel import gptq as gptq_mod
+
+    groups: dict[tp.Any, list[LinearEntry]] = {}
+    for e in entries:
+        groups.setdefault(gptq_mod.inputs_key(layer_cache[e.name].inputs.front(), device), []).append(e)
+
+    def cost(members):  # ~ C^3 for the inverse factor + R C^2 for the sweeps
+        c = members[0].module.in_features
+        return c * c * (c + sum(m.module.out_features for m in members))
+
+    return sorted(groups.values(), key=cost, reverse=True), cost
+
+
+def prepare_layer_hessians(entries: tp.Sequence[LinearEntry], layer_cache: dict[str, IOTensorsCache],
+                           hessian_hook: tp.Callable[[int], tp.Any] | None = None) -> None:
+    """Queue the Hessians of a layer that ``quantize_layer_weights(..., streams > 1)`` will be called for NEXT, on the
+    current stream, in the order that call would compute them (largest pipeline first).  To be passed as the
+    ``prefetch`` of the call for the layer before it; they are kept until the end of the next call."""
+    from ..quantizer.kernel import gptq as gptq_mod
+
+    device = entries[0].module.weight.device
+    order, _ = _groups_by_inputs(entries, layer_cache, device)
+    # beside the running layer's chains of single-workgroup kernels: an eighth of the compute units is left alone
+    width = torch.cuda.get_device_properties(device).multi_processor_count * 7 // 8
+    for members in order:
+        events = hessian_hook(members[0].module.in_features) if hessian_hook is not None else None
+        gptq_mod.prepare_hessians([layer_cache[members[0].name].inputs.front()], device, round_width=width,
+                                  profile_events=events, ahead=True)
 
 
 def _row_multiple(config: LlmWeightQuantizerConfig) -> int:
@@ -271,33 +315,32 @@ def _quantize_layer_weights_row_sharded(entries, config, quantizer_state_dict, l
 
 
 def _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, layer_cache, return_with_scale_state_dict,
-                                       develop_dtype, streams, hessian_hook) -> dict[str, torch.Tensor | float | None]:
+                                       develop_dtype, streams, hessian_hook,
+                                       prefetch=None) -> dict[str, torch.Tensor | float | None]:
     from ..parallel import assign_by_cost, run_on_streams
     from ..quantizer.kernel import gptq as gptq_mod
 
     device = entries[0].module.weight.device
-    groups: dict[tp.Any, list[LinearEntry]] = {}
-    for e in entries:
-        groups.setdefault(gptq_mod.inputs_key(layer_cache[e.name].inputs.front(), device), []).append(e)
-
-    def cost(members):  # ~ C^3 for the inverse factor + R C^2 for the sweeps
-        c = members[0].module.in_features
-        return c * c * (c + sum(m.module.out_features for m in members))
-
-    order = sorted(groups.values(), key=cost, reverse=True)
+    order, cost = _groups_by_inputs(entries, layer_cache, device)
     start = torch.cuda.Event()
     start.record()
     ready = []
+    ahead = []  # the group's Hessian was prepared during the previous layer's call
     # The first (largest) Hessian has the chip to itself.  The later ones run beside the first group's factorisation,
     # a chain of single-workgroup kernels that each need a free compute unit to start on, so they leave an eighth of
     # the compute units alone (measured: 120-122 -> 118-119 ms per Llama-3-8B layer; 3/4 and 15/16 gain less).
     width = torch.cuda.get_device_properties(device).multi_processor_count * 7 // 8
     for n, members in enumerate(order):
-        events = hessian_hook(members[0].module.in_features) if hessian_hook is not None else None
-        gptq_mod.prepare_hessians([layer_cache[members[0].name].inputs.front()], device,
-                                  round_width=width if n > 0 else 0, profile_events=events)
-        ready.append(torch.cuda.Event())
-        ready[-1].record()
+        inputs = layer_cache[members[0].name].inputs.front()
+        ahead.append(gptq_mod.is_prepared(inputs, device))
+        events = hessian_hook(members[0].module.in_features) if hessian_hook is not None and not ahead[-1] else None
+        hessian = gptq_mod.prepare_hessians([inputs], device, round_width=width if n > 0 else 0, profile_events=events)[0]
+        ready.append(getattr(hessian, "_dcq_ready", None))
+        if ready[-1] is None:
+            ready[-1] = torch.cuda.Event()
+            ready[-1].record()
+    if prefetch is not None:
+        prefetch()
     # longest pipeline first, the rest dealt to the least loaded stream (each list ascending = order of readiness)
     buckets = [b for b in assign_by_cost([float(cost(members)) for members in order], min(streams, len(order))) if b]
 
@@ -312,7 +355,7 @@ def _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, la
             # HBM) that precedes the first SYRK, instead of between that SYRK and the group's factorisation (-0.65 ms
             # per Llama-3-8B layer over six A/B pairs).  For the later groups the same move only takes compute units
             # from a SYRK.
-            early = i == 0
+            early = i == 0 and not ahead[0]
             if not early:
                 wait()
             parts.append(_quantize_layer_weights(order[i], config, quantizer_state_dict, layer_cache,
@@ -327,7 +370,8 @@ def _quantize_layer_weights_on_streams(entries, config, quantizer_state_dict, la
     # from one path to the other).
     prio = [-1] + [0] * (len(buckets) - 1)
     results = run_on_streams([lambda b=b: run_bucket(b) for b in buckets], device=device,
-                             after=[start if b[0] == 0 else ready[b[0]] for b in buckets],
+                             # (a Hessian prepared ahead was ready before this call's inputs may have been: `start`)
+                             after=[start if b[0] == 0 or ahead[b[0]] else ready[b[0]] for b in buckets],
                              priorities=prio)
     for copy in pending:
         copy()

@@ -89,21 +89,25 @@ class _State(threading.local):
 _state = _State()
 # Hessians computed ahead of time by ``prepare_hessians`` (any number, visible to every host thread) until
 # ``clear_hessian_cache``; read-only once stored.
-_prepared: dict = {}  # key -> (activation tensors held alive, Hessian)
+_prepared: dict = {}  # key -> (activation tensors held alive, Hessian, prepared ahead for the next layer)
 _prepared_lock = threading.Lock()
 PREPARED_LIMIT = 16  # prepared Hessians kept at most (oldest dropped first): a caller that never clears stays bounded
 
 
-def clear_hessian_cache() -> None:
-    """Drop this thread's memoised Hessian and inverse factor, and every prepared Hessian."""
+def clear_hessian_cache(keep_ahead: bool = False) -> None:
+    """Drop this thread's memoised Hessian and inverse factor, and every prepared Hessian.  ``keep_ahead``: the
+    Hessians prepared with ``ahead=True`` (the next layer's, computed beside this layer's pipelines) stay, as ordinary
+    entries from now on -- the next call drops them."""
     _state.hessian["key"] = _state.hessian["refs"] = _state.hessian["value"] = None
     _state.factor["key"] = _state.factor["value"] = None
     with _prepared_lock:
+        kept = {k: (refs, h, False) for k, (refs, h, ahead) in _prepared.items() if ahead} if keep_ahead else {}
         _prepared.clear()
+        _prepared.update(kept)
 
 
 def prepare_hessians(caches, device: torch.device, world: int = 1, round_width: int = 0,
-                     profile_events: tuple | None = None) -> list[torch.Tensor]:
+                     profile_events: tuple | None = None, ahead: bool = False) -> list[torch.Tensor]:
     """Compute the Hessian of every activation cache in ``caches`` now, one after the other on the current stream
     (each launch has the whole chip), and keep them for ``hessian_of`` calls from any thread until
     ``clear_hessian_cache`` -- call that when the layer is done: every entry holds its cache's activation tensors
@@ -120,7 +124,10 @@ def prepare_hessians(caches, device: torch.device, world: int = 1, round_width: 
     ``round_width`` > 0: the SYRK takes at most that many compute units at a time, for Hessians computed while
     latency-bound kernels of other streams need a free compute unit to start on.  ``profile_events``: a pair of
     ``torch.cuda.Event(enable_timing=True)`` recorded right before / after the SYRK launches of the first cache that
-    is not already prepared (a measurement hook)."""
+    is not already prepared (a measurement hook).  ``ahead``: these are the NEXT layer's Hessians, queued while the
+    current layer's pipelines run; they survive the ``clear_hessian_cache(keep_ahead=True)`` that ends the current
+    layer.  Every Hessian computed here carries ``_dcq_ready``, an event recorded on the current stream right behind
+    its kernels, for consumers on other streams."""
     from ...parallel import all_reduce_sum
 
     out = []
@@ -137,8 +144,10 @@ def prepare_hessians(caches, device: torch.device, world: int = 1, round_width: 
                                                       round_width=round_width, profile_events=events), world)
             else:
                 hit = _compute_hessian(inputs, device, round_width=round_width, profile_events=events)
+            hit._dcq_ready = torch.cuda.Event()
+            hit._dcq_ready.record()
             with _prepared_lock:
-                _prepared[key] = (tuple(inputs.data), hit)
+                _prepared[key] = (tuple(inputs.data), hit, ahead)
                 while len(_prepared) > PREPARED_LIMIT:
                     _prepared.pop(next(iter(_prepared)))
         out.append(hit)
@@ -155,6 +164,11 @@ def _prepared_lookup(key, inputs: TensorCache):
     if entry is not None and _same_tensors(entry[0], inputs):
         return entry[1]
     return None
+
+
+def is_prepared(inputs: TensorCache, device: torch.device) -> bool:
+    """A Hessian for this cache has been computed by ``prepare_hessians`` and is still kept."""
+    return _prepared_lookup(_inputs_key(inputs, device), inputs) is not None
 
 
 def cached_hessian_key():

@@ -9,7 +9,7 @@ from _product import to_device, to_np
 from _stage import stage_config
 from conftest import assert_bit_equal, load_golden
 
-from deepcompressor_amd.app import (LinearEntry, load_weight_checkpoint, quantize_layer_weights,
+from deepcompressor_amd.app import (LinearEntry, load_weight_checkpoint, prepare_layer_hessians, quantize_layer_weights,
                                     save_weight_checkpoint)
 from deepcompressor_amd.data.cache import IOTensorsCache, TensorCache, TensorsCache
 from deepcompressor_amd.data.utils.reshape import LinearReshapeFn
@@ -235,6 +235,46 @@ def test_weight_stage_stacks_the_weights_of_a_group(monkeypatch):
 
     for name in want_state:
         assert same(want_state[name], got_state[name]), name
+
+
+def test_weight_stage_prefetches_the_next_layers_hessians():
+    """Two layers one after the other, the first call queueing the second layer's Hessians (``prefetch``): the second
+    call computes none (its hook stays silent), both layers come out bit-equal to the stage without prefetching, and
+    nothing prepared is left behind."""
+    from deepcompressor_amd.quantizer.kernel import gptq as gptq_mod
+
+    tag = "gptq_r_rtn"
+    m = LS.meta[tag]
+    config = stage_config(m["case"], kernel_gptq=QuantGptqConfig())
+
+    def layer(seed):
+        g = torch.Generator().manual_seed(seed)
+        plain, piped = build_layer(tag), build_layer(tag)
+        shared, cache = {}, {}
+        for e in plain:
+            c = e.module.in_features
+            if c not in shared:
+                x = (torch.randn(4, 256, c, generator=g) * torch.exp(0.7 * torch.randn(c, generator=g))).to(torch.float16).cuda()
+                shared[c] = TensorCache([x], channels_dim=-1, reshape=LinearReshapeFn(), num_cached=1, num_total=1,
+                                        num_samples=1024, orig_device=x.device)
+            cache[e.name] = IOTensorsCache(inputs=TensorsCache(shared[c]))
+        return plain, piped, cache, len(shared)
+
+    plain1, piped1, cache1, groups = layer(21)
+    plain2, piped2, cache2, _ = layer(22)
+    for entries, cache in ((plain1, cache1), (plain2, cache2)):
+        quantize_layer_weights(entries, config, {}, layer_cache=cache, streams=3)
+    first, ahead, second = [], [], []
+    quantize_layer_weights(piped1, config, {}, layer_cache=cache1, streams=3, hessian_hook=first.append,
+                           prefetch=lambda: prepare_layer_hessians(piped2, cache2, hessian_hook=ahead.append))
+    assert len(first) == groups and len(ahead) == groups
+    assert all(gptq_mod.is_prepared(cache2[e.name].inputs.front(), torch.device("cuda", 0)) for e in piped2)
+    assert not any(gptq_mod.is_prepared(cache1[e.name].inputs.front(), torch.device("cuda", 0)) for e in piped1)
+    quantize_layer_weights(piped2, config, {}, layer_cache=cache2, streams=3, hessian_hook=second.append)
+    assert second == [], second
+    assert not gptq_mod._prepared
+    for a, b in zip(plain1 + plain2, piped1 + piped2):
+        assert torch.equal(a.module.weight.data, b.module.weight.data), a.name
 
 
 def test_activation_stage_calibrates_reloads_and_hooks():

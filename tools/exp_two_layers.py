@@ -5,6 +5,7 @@ import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
+bench.torch = torch
 from deepcompressor_amd import parallel
 from deepcompressor_amd.quantizer.kernel import gptq as gptq_mod
 
@@ -22,12 +23,12 @@ def job_stream(dev, slot, prio):
     return orig_job_stream(dev, slot + 10 * getattr(tls, "index", 0), prio)
 parallel._job_stream = job_stream
 
-def clear_own():
+def clear_own(keep_ahead=False):
     gptq_mod._state.hessian["key"] = gptq_mod._state.hessian["refs"] = gptq_mod._state.hessian["value"] = None
     gptq_mod._state.factor["key"] = gptq_mod._state.factor["value"] = None
     own = {id(t) for t in tls.tensors}
     with gptq_mod._prepared_lock:
-        for key in [k for k, (refs, _) in gptq_mod._prepared.items() if any(id(t) in own for t in refs)]:
+        for key in [k for k, (refs, *_) in gptq_mod._prepared.items() if any(id(t) in own for t in refs)]:
             del gptq_mod._prepared[key]
 gptq_mod.clear_hessian_cache = clear_own
 
