@@ -83,6 +83,7 @@ _SIGNATURES = {
     "dcq_gemm_f32_two_term": [_p, _i64, _i32, _p, _i64, _p, _i64, _i64, _i64, _i64, _f, _f, _p, _i64, _p],
     "dcq_cholesky_inverse_upper": [_p, _i64, _p, _f, _p, _p, _i64, _p, _p],
     "dcq_cholesky_inverse_upper_static": [_p, _i64, _p, _f, _p, _p, _p],
+    "dcq_gram_inverse_factor_f64": [_p, _i64, _i32, _p, _i64, _p, _p],
     "dcq_gemm_f64": [_p, _i32, _i64, _i32, _i64, _p, _i32, _i64, _i64, _p, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "dcq_fake_quant_groups_outer": [C.POINTER(Step), _p, _i32, _i64, _i64, _p, _f, _f, _i32, _f, _f, _p, _p, _i32, _f, _p,
                                     _i32, _p, _p, _p, _p, _p],

@@ -6,6 +6,8 @@
 // accumulated by v_mfma_f64_16x16x4_f64 (an exact float64 fma chain), and the epilogue rounds double -> float ->
 // storage exactly as the reference's cast does.  Operand storage types are run-time parameters (uniform
 // branches): the float64 matrix instruction takes 64 cycles, staging is not the bottleneck.
+#include <atomic>
+
 #include "dcq_common.cuh"
 
 namespace dcq {
@@ -174,6 +176,78 @@ __global__ __launch_bounds__(kDThreads) void gemm_f64_kernel(const Gemm64Params 
       }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Inverse Cholesky factor of a small float64 Gram matrix, for Cholesky QR (x <- x R^-1 with R^T R = x^T x): one
+// workgroup, the matrix in LDS.  Cholesky elimination on [S | I], S = (G + G^T) / 2: after pivot j row j of the left
+// part is row j of R and row j of the right part is row j of R^-T, and neither is read again -- only row j of R^-T
+// is kept (it is column j of the output X = R^-1), in the place of the pivot row.  The right part is lower
+// triangular and lives in the strict lower triangle of the same k x k array (its diagonal is 1 / R[j][j]).
+// Thread (slot, c) keeps column c and takes the rows j + 1 + slot, + 4, ... : one barrier per pivot.
+// info: 1-based index of the first non-positive pivot, or 0 (the arithmetic then runs on NaNs, harmlessly).
+// ---------------------------------------------------------------------------------------------
+constexpr int kGramMax = 128;      // order of the largest matrix: 128 KiB of LDS
+constexpr int kGramThreads = 512;  // 4 row slots x 128 columns
+
+__global__ __launch_bounds__(kGramThreads) void gram_inverse_factor_kernel(const double* __restrict__ G, int64_t ldg, int k,
+                                                                            double* __restrict__ X, int64_t ldx,
+                                                                            int32_t* __restrict__ info) {
+  extern __shared__ __align__(16) unsigned char gram_smem[];
+  double* M = reinterpret_cast<double*>(gram_smem);  // [k][k]
+  const int c = threadIdx.x & (kGramMax - 1), slot = threadIdx.x >> 7;
+  for (int e = threadIdx.x; e < k * k; e += kGramThreads) {
+    const int i = e / k, j = e - i * k;
+    M[e] = j >= i ? 0.5 * (G[i * ldg + j] + G[j * ldg + i]) : 0.0;
+  }
+  __syncthreads();
+  int bad = 0;
+  double finished = 0.0;
+  for (int j = 0; j < k; ++j) {
+    const double djj = M[j * k + j];
+    if (bad == 0 && !(djj > 0.0)) bad = j + 1;
+    // 1 / sqrt(djj): the hardware's estimate and two Newton steps (the first squares its 2^-26, the second ends at
+    // rounding level) instead of a square root and a division in software
+    double inv = __builtin_amdgcn_rsq(djj);
+    inv = inv * (1.5 - 0.5 * djj * inv * inv);
+    inv = inv * (1.5 - 0.5 * djj * inv * inv);
+    if (c < k) {
+      // this column's entry of the scaled pivot row: R^-T[j][c] (c < j), 1 / R[j][j] (c = j), R[j][c] (c > j)
+      const double rjc = c == j ? inv : M[j * k + c] * inv;
+      // the finished row j - 1 of R^-T replaces pivot row j - 1, which nobody reads any more (not row j of this
+      // step: the other slots are still reading it; and not global memory: a barrier would wait for the stores)
+      if (slot == 0 && j > 0) M[(j - 1) * k + c] = finished;
+      finished = rjc;
+      // Rows j + 1 + slot, + 4, ... up to `last`: a column of the right part (c <= j) takes every row below the pivot
+      // (its entry in row i, column j starts as the zero the lower triangle was loaded with), a column of the left
+      // part the rows down to its diagonal; what lies between, the right part's zeros of later pivots, stays.  Eight
+      // rows at a time, all LDS reads of a batch ahead of its arithmetic and writes (the compiler cannot tell that
+      // the writes leave the pivot row alone), then the rest one by one.
+      const int last = c <= j ? k - 1 : c;
+      int i = j + 1 + slot;
+      for (; i + 28 <= last; i += 32) {
+        double a[8], old[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a[u] = M[j * k + i + 4 * u];  // R[j][i] before scaling
+          old[u] = M[(i + 4 * u) * k + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) M[(i + 4 * u) * k + c] = old[u] - (a[u] * inv) * rjc;
+      }
+      for (; i <= last; i += 4) M[i * k + c] = M[i * k + c] - (M[j * k + i] * inv) * rjc;
+    }
+    __syncthreads();
+  }
+  if (slot == 0 && c < k) M[(k - 1) * k + c] = finished;
+  __syncthreads();
+  // X = (R^-T)^T, zeros below the diagonal: LDS rows read along c, the scattered 8-byte stores all in flight together
+  for (int e = threadIdx.x; e < k * k; e += kGramThreads) {
+    const int j = e / k, cc = e - j * k;
+    X[cc * ldx + j] = cc <= j ? M[e] : 0.0;
+  }
+  if (threadIdx.x == 0) *info = bad;
+}
+
 }  // namespace dcq
 
 using namespace dcq;
@@ -218,5 +292,29 @@ extern "C" int dcq_gemm_f64(const void* A, int32_t a_storage, int64_t lda, int32
   const dim3 grid(static_cast<unsigned>(p.tiles_m) * static_cast<unsigned>(p.tiles_n), static_cast<unsigned>(batch));
   hipLaunchKernelGGL(gemm_f64_kernel, grid, dim3(kDThreads), 0, static_cast<hipStream_t>(stream), p);
   DCQ_LAUNCH_CHECK("gemm_f64_kernel launch");
+  return DCQ_OK;
+}
+
+extern "C" int dcq_gram_inverse_factor_f64(const double* G, int64_t ldg, int32_t k, double* X, int64_t ldx, int32_t* info,
+                                           dcq_stream_t stream) {
+  using namespace dcq;
+  DCQ_REQUIRE(G && X && info, DCQ_ERR_ARGUMENT, "NULL buffer");
+  DCQ_REQUIRE(k >= 1 && ldg >= k && ldx >= k, DCQ_ERR_ARGUMENT, "bad sizes");
+  DCQ_REQUIRE(k <= kGramMax, DCQ_ERR_UNSUPPORTED, "order %d: at most %d (the matrix is kept in LDS)", k, kGramMax);
+  const size_t lds = static_cast<size_t>(k) * k * sizeof(double);
+  static std::atomic<bool> configured[64];
+  int dev = 0;
+  int rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
+  if (rc != DCQ_OK) return rc;
+  if (dev < 0 || dev >= 64 || !configured[dev]) {
+    rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_inverse_factor_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kGramMax * kGramMax * 8),
+                   "hipFuncSetAttribute(gram LDS)");
+    if (rc != DCQ_OK) return rc;
+    if (dev >= 0 && dev < 64) configured[dev] = true;
+  }
+  hipLaunchKernelGGL(gram_inverse_factor_kernel, dim3(1), dim3(kGramThreads), lds, static_cast<hipStream_t>(stream), G, ldg,
+                     k, X, ldx, info);
+  DCQ_LAUNCH_CHECK("gram_inverse_factor_kernel launch");
   return DCQ_OK;
 }

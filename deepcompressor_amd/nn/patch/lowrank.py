@@ -56,17 +56,42 @@ BLOCK = 128  # vectors iterated together (the wanted ones plus a margin that set
 FILTER_PASSES = 2  # filter + orthonormalization passes between two Rayleigh-Ritz steps
 
 
+GRAM_KERNEL_ORDER = 128  # largest k x k Gram matrix that ``dcq_gram_inverse_factor_f64`` keeps in LDS
+
+
+def _gram_inverse_factor(gram: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """(R^-1, info) with R^T R = (gram + gram^T) / 2, R upper triangular: ``cholesky_ex`` + ``solve_triangular``
+    against the identity in one launch (float64, order <= GRAM_KERNEL_ORDER)."""
+    import ctypes as C
+
+    from ..._lib import check, lib, stream_of
+
+    raw = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    k = gram.shape[0]
+    assert gram.dtype == torch.float64 and gram.shape == (k, k) and gram.is_contiguous()
+    r_inv = torch.empty_like(gram)
+    info = torch.empty(1, dtype=torch.int32, device=gram.device)
+    check(lib().dcq_gram_inverse_factor_f64(raw(gram), k, k, raw(r_inv), k, raw(info), stream_of(gram.device)),
+          "dcq_gram_inverse_factor_f64")
+    return r_inv, info[0]
+
+
 def _orthonormalize(x: torch.Tensor) -> torch.Tensor:
     """Columns of x [n][k] orthonormalized by two rounds of Cholesky QR (x <- x R^-1 with R^T R = x^T x): everything
     large is a float64 matrix-core product, the k x k factorisations are the only small dense routines."""
-    eye = torch.eye(x.shape[1], dtype=x.dtype, device=x.device)
+    k = x.shape[1]
+    eye = None if k <= GRAM_KERNEL_ORDER else torch.eye(k, dtype=x.dtype, device=x.device)
     given, failed = x, None
     for _ in range(2):
         gram = _split_k_f64(x, x, a_transposed=True)
-        gram = (gram + gram.t()) * 0.5
-        r, info = torch.linalg.cholesky_ex(gram, upper=True)
+        if eye is None:  # symmetrized, factored and inverted by one workgroup with the matrix in LDS
+            r_inv, info = _gram_inverse_factor(gram)
+        else:
+            gram = (gram + gram.t()) * 0.5
+            r, info = torch.linalg.cholesky_ex(gram, upper=True)
+            r_inv = torch.linalg.solve_triangular(r, eye, upper=True)
         failed = info if failed is None else failed | info
-        x = _split_k_f64(x, torch.linalg.solve_triangular(r, eye, upper=True), splits=1)
+        x = _split_k_f64(x, r_inv, splits=1)
     # both rounds are queued before the host looks at the factorisations' flags (one read instead of two waits)
     if int(failed.item()) != 0:  # columns (numerically) dependent: the slow but unconditional route
         return torch.linalg.qr(given).Q

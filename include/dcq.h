@@ -419,6 +419,15 @@ int dcq_gemm_f64(const void* A, int32_t a_storage, int64_t lda, int32_t a_kmajor
                  int32_t b_storage, int64_t ldb, int64_t b_batch_stride, void* C, int32_t c_storage, int64_t ldc,
                  int64_t c_batch_stride, int64_t M, int64_t N, int64_t K, int64_t batch, dcq_stream_t stream);
 
+/* dcq_gram_inverse_factor_f64: X = R^-1 (upper triangular, zeros below) with R^T R = (G + G^T) / 2 for a float64
+ * matrix G of order k <= 128, one workgroup with the matrix in LDS.  The small dense step of Cholesky QR in the
+ * low-rank branch's eigen-solve, which keeps the `rank` leading triplets of the SVD the reference takes in full
+ * (deepcompressor/nn/patch/lowrank.py:49-59); stands for `cholesky_ex(G, upper=True)` followed by
+ * `solve_triangular(R, eye, upper=True)`.  *info: 0, or the 1-based index of the first non-positive pivot (X is
+ * then meaningless).  Larger orders: DCQ_ERR_UNSUPPORTED. */
+int dcq_gram_inverse_factor_f64(const double* G, int64_t ldg, int32_t k, double* X, int64_t ldx, int32_t* info,
+                                dcq_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Smooth quantization (deepcompressor/calib/metric.py:31-86, calib/smooth.py:56-78, 852-891).
  *

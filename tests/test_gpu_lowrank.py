@@ -121,6 +121,46 @@ def test_leading_triplets_match_full_svd_at_model_size(shape):
     assert eff.dtype == w.dtype and (eff.double() - us @ vh).abs().max() < 2e-2 * float(sigma[0]) / 32
 
 
+@pytest.mark.parametrize("k", [1, 7, 64, 100, 128])
+def test_gram_inverse_factor_matches_float64_lapack(k):
+    """The one-launch inverse Cholesky factor of a small Gram matrix (Cholesky QR's dense step) against
+    cholesky + solve_triangular in float64: X upper triangular with exact zeros below, X^T G X = I, and the same
+    numbers as the LAPACK route to rounding."""
+    from deepcompressor_amd.nn.patch.lowrank import _gram_inverse_factor
+
+    g = torch.Generator().manual_seed(k)
+    a = torch.randn(3 * k + 5, k, generator=g, dtype=torch.float64) * torch.exp(torch.randn(k, generator=g, dtype=torch.float64))
+    gram = (a.T @ a).cuda()
+    noisy = gram + 1e-13 * float(gram.abs().max()) * torch.randn(k, k, generator=g, dtype=torch.float64).cuda()  # not symmetric
+    x, info = _gram_inverse_factor(noisy.contiguous())
+    assert int(info) == 0
+    assert torch.equal(x.tril(-1), torch.zeros_like(x))
+    sym = (noisy + noisy.T) * 0.5
+    want = torch.linalg.solve_triangular(torch.linalg.cholesky(sym, upper=True), torch.eye(k, dtype=torch.float64, device="cuda"),
+                                         upper=True)
+    scale = want.abs().max()
+    assert (x - want).abs().max() <= 1e-9 * scale, float((x - want).abs().max() / scale)
+    eye = x.T @ sym @ x
+    assert (eye - torch.eye(k, dtype=torch.float64, device="cuda")).abs().max() < 1e-8
+
+
+def test_gram_inverse_factor_reports_the_first_bad_pivot_and_refuses_large_orders():
+    from deepcompressor_amd._lib import DcqError
+    from deepcompressor_amd.nn.patch.lowrank import _gram_inverse_factor
+
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(40, 32, generator=g, dtype=torch.float64)
+    a[:, 20] = a[:, 3] * 2.0 - a[:, 7]  # column 20 depends on earlier ones: pivot 21 is (numerically) not positive
+    gram = (a.T @ a).cuda()
+    gram[20, 20] -= 1e-6
+    _, info = _gram_inverse_factor(gram)
+    assert int(info) == 21, int(info)
+    _, ok = _gram_inverse_factor(torch.eye(32, dtype=torch.float64, device="cuda"))
+    assert int(ok) == 0
+    with pytest.raises(DcqError):
+        _gram_inverse_factor(torch.eye(129, dtype=torch.float64, device="cuda"))
+
+
 BR = load_golden("branch")
 
 
