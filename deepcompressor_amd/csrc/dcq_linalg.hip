@@ -78,12 +78,9 @@ __device__ __forceinline__ float4 load_piece(const float* row, int col, int limi
 
 // One T x T tile of C by 4 waves (2 x 2 quadrants of T/2 x T/2, each T/64 x T/64 matrix-instruction tiles).
 // T = 128 for throughput; T = 64 spreads small problems over 4x as many compute units (latency-bound regime).
-// `tid` (0..255) is the thread's index in the group of 256 that computes this tile; `extra_barriers` are executed
-// after the tile's own 1 + nk workgroup barriers (a workgroup running two tiles side by side, one per half, keeps
-// both halves on the same barrier count).
+// `tid` (0..255) is the thread's index in the workgroup.
 template <bool A_KMAJOR, bool FAST, int T>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m0, int n0, int k_begin, int nk,
-                                          int tid, int extra_barriers = 0) {
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m0, int n0, int k_begin, int nk, int tid) {
   constexpr int kGK = GemmStep<T>::value;
   constexpr int LD = T + 4;              // LDS row pitch: the two half-waves of a fragment read hit different banks
   constexpr int IMG = kGK * LD;          // one operand image [k][m or n]
@@ -184,7 +181,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m
           *c = p.beta == 0.0f ? v : p.beta * *c + v;
         }
       }
-  for (int i = 0; i < extra_barriers; ++i) __syncthreads();
 }
 
 template <bool A_KMAJOR, int T>

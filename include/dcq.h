@@ -424,7 +424,7 @@ int dcq_gemm_f64(const void* A, int32_t a_storage, int64_t lda, int32_t a_kmajor
  * low-rank branch's eigen-solve, which keeps the `rank` leading triplets of the SVD the reference takes in full
  * (deepcompressor/nn/patch/lowrank.py:49-59); stands for `cholesky_ex(G, upper=True)` followed by
  * `solve_triangular(R, eye, upper=True)`.  *info: 0, or the 1-based index of the first non-positive pivot (X is
- * then meaningless).  Larger orders: DCQ_ERR_UNSUPPORTED. */
+ * then meaningless).  X must not overlap G.  Larger orders: DCQ_ERR_UNSUPPORTED. */
 int dcq_gram_inverse_factor_f64(const double* G, int64_t ldg, int32_t k, double* X, int64_t ldx, int32_t* info,
                                 dcq_stream_t stream);
 
