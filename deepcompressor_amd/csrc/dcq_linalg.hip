@@ -315,9 +315,11 @@ __device__ __forceinline__ void half_scale_of(unsigned absmax_bits, float& scale
 __device__ __forceinline__ int split_row_of(int s) { return 64 * (s >> 6) + 4 * (s & 15) + ((s >> 4) & 3); }
 
 // Result of one 128 x 128 tile: lane (g, j) of block (i, n) holds C[64 wr + 16 g + 4 r + i][64 wc + 4 j + n], r = 0..3
+// `c_old`: the tile's own values of C, [i][r] in the order below, when the caller has fetched them already
+// (`have_old`: whole tiles with beta != 0 only).
 template <int PLANES>
 __device__ __forceinline__ void split_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int wr, int wc,
-                                               int g, int j) {
+                                               int g, int j, const float4 (&c_old)[4][4], bool have_old) {
   const bool whole = m0 + 128 <= p.M && n0 + 128 <= p.N && p.vec_c;  // uniform
   float back_b[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // two-term path: the scales are taken out again, exactly
   if constexpr (PLANES == 2) {
@@ -344,7 +346,7 @@ __device__ __forceinline__ void split_epilogue(const GemmParams& p, const f32x4 
       if (whole) {
         float4 out = make_float4(v[0], v[1], v[2], v[3]);
         if (p.beta != 0.0f) {
-          const float4 old = *reinterpret_cast<const float4*>(c);
+          const float4 old = have_old ? c_old[i][r] : *reinterpret_cast<const float4*>(c);
           out = make_float4(p.beta * old.x + v[0], p.beta * old.y + v[1], p.beta * old.z + v[2], p.beta * old.w + v[3]);
         }
         *reinterpret_cast<float4*>(c) = out;
@@ -473,7 +475,8 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
     step(kt, 1, 0);
     if (kt + 1 < nk) step(kt + 1, 0, 1);
   }
-  split_epilogue<3>(p, acc, m0, n0, wr, wc, g, j);
+  const float4 none[4][4] = {};
+  split_epilogue<3>(p, acc, m0, n0, wr, wc, g, j, none, false);
 }
 
 template <bool A_KMAJOR>
@@ -669,6 +672,19 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_planes_kernel(const Gemm
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[i][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // C += ...: the tile's values of C are requested ahead of the operands, so that the epilogue does not start with a
+  // round trip to memory (a short reduction -- the sweeps' K = 512 -- is over in 16 steps)
+  const bool fetch_c = p.beta != 0.0f && m0 + 128 <= p.M && n0 + 128 <= p.N && p.vec_c;  // uniform
+  float4 c_old[4][4];
+  if (fetch_c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        c_old[i][r] = *reinterpret_cast<const float4*>(p.C + static_cast<int64_t>(m0 + 64 * wr + 16 * g + 4 * r + i) * p.ldc +
+                                                       n0 + 64 * wc + 4 * j);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if (nk > 0) {  // uniform over the workgroup
     const unsigned char* ga = p.a_planes + (static_cast<int64_t>(tm) * ksteps + ks0) * kImageBytes + tid * 16;
     const unsigned char* gb = p.b_planes + (static_cast<int64_t>(tn) * ksteps + ks0) * kImageBytes +
@@ -699,7 +715,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_planes_kernel(const Gemm
     }
     if (kt < nk) planes_step(kt, nk, ga, gb, gemm_smem, tid, frag_a, acc, ra1, b0);
   }
-  split_epilogue<2>(p, acc, m0, n0, wr, wc, g, j);
+  split_epilogue<2>(p, acc, m0, n0, wr, wc, g, j, c_old, fetch_c);
 }
 
 // Largest magnitudes for the two-term path, as float32 bit patterns (which order like the magnitudes; a NaN sorts
