@@ -167,20 +167,44 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, float* lds, int m
   }
   const int col_in = lane & 31, row_off = 4 * (lane >> 5);
   const bool inside = m0 + T <= p.M && n0 + T <= p.N;  // uniform
+  // Whole tiles take a branch-free path: the 16 values of C that a 32 x 32 block accumulates into are all requested
+  // before the first is used, and the 16 results stand in registers of their own before the first store.  Taken one by
+  // one behind a bounds check each, every read waits for the store before it (loads and stores share one counter) --
+  // sixteen round trips to memory at the end of a product that may be eight K steps long.
 #pragma unroll
   for (int m = 0; m < F; ++m)
 #pragma unroll
-    for (int n = 0; n < F; ++n)
+    for (int n = 0; n < F; ++n) {
+      const int col = n0 + wc * (T / 2) + n * 32 + col_in;
+      const int row0 = m0 + wr * (T / 2) + m * 32 + row_off;
+      float* c0 = p.C + static_cast<int64_t>(row0) * p.ldc + col;
+      if (inside) {
+        float out[16];
+        if (p.beta != 0.0f) {  // uniform
+          float old[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * (T / 2) + m * 32 + (r & 3) + 8 * (r >> 2) + row_off;
-        const int col = n0 + wc * (T / 2) + n * 32 + col_in;
-        if (inside || (row < p.M && col < p.N)) {
-          float* c = p.C + static_cast<int64_t>(row) * p.ldc + col;
-          const float v = p.alpha * acc[m][n][r];
-          *c = p.beta == 0.0f ? v : p.beta * *c + v;
+          for (int r = 0; r < 16; ++r) old[r] = c0[static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * p.ldc];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[r] = p.beta * old[r] + p.alpha * acc[m][n][r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[r] = p.alpha * acc[m][n][r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0[static_cast<int64_t>((r & 3) + 8 * (r >> 2)) * p.ldc] = out[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int up = (r & 3) + 8 * (r >> 2);
+          if (row0 + up < p.M && col < p.N) {
+            float* c = c0 + static_cast<int64_t>(up) * p.ldc;
+            const float v = p.alpha * acc[m][n][r];
+            *c = p.beta == 0.0f ? v : p.beta * *c + v;
+          }
         }
       }
+    }
 }
 
 template <bool A_KMAJOR, int T>
