@@ -340,16 +340,52 @@ __device__ __forceinline__ int split_row_of(int s) { return 64 * (s >> 6) + 4 * 
 
 // Result of one 128 x 128 tile: lane (g, j) of block (i, n) holds C[64 wr + 16 g + 4 r + i][64 wc + 4 j + n], r = 0..3
 // `c_old`: the tile's own values of C, [i][r] in the order below, when the caller has fetched them already
-// (`have_old`: whole tiles with beta != 0 only).
-template <int PLANES>
+// (HAVE_OLD: whole tiles with beta != 0 only).
+template <int PLANES, bool HAVE_OLD>
 __device__ __forceinline__ void split_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int wr, int wc,
-                                               int g, int j, const float4 (&c_old)[4][4], bool have_old) {
+                                               int g, int j, const float4 (&c_old)[4][4]) {
   const bool whole = m0 + 128 <= p.M && n0 + 128 <= p.N && p.vec_c;  // uniform
   float back_b[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // two-term path: the scales are taken out again, exactly
   if constexpr (PLANES == 2) {
     float unused;
 #pragma unroll
     for (int e = 0; e < 4; ++e) half_scale_of(p.b_absmax[min(n0 + 64 * wc + 4 * j + e, p.N - 1)], unused, back_b[e]);
+  }
+  // (whole tiles and tiles on an edge in loops of their own, and the rows' magnitudes fetched ahead of the loop: with
+  // bounds checks and loads between the stores every store waits for the one before it -- loads and stores share one
+  // counter)
+  if (whole) {
+    unsigned a_bits[4][4];
+    if constexpr (PLANES == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a_bits[i][r] = p.a_absmax[m0 + 64 * wr + 16 * g + 4 * r + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 64 * wr + 16 * g + 4 * r + i, col = n0 + 64 * wc + 4 * j;
+        float v[4];
+        if constexpr (PLANES == 2) {
+          float unused, back_a;
+          half_scale_of(a_bits[i][r], unused, back_a);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = p.alpha * ((acc[i][e][r] * back_a) * back_b[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = p.alpha * acc[i][e][r];
+        }
+        float* c = p.C + static_cast<int64_t>(row) * p.ldc + col;
+        float4 out = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.beta != 0.0f) {
+          const float4 old = HAVE_OLD ? c_old[i][r] : *reinterpret_cast<const float4*>(c);
+          out = make_float4(p.beta * old.x + v[0], p.beta * old.y + v[1], p.beta * old.z + v[2], p.beta * old.w + v[3]);
+        }
+        *reinterpret_cast<float4*>(c) = out;
+      }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -367,14 +403,7 @@ __device__ __forceinline__ void split_epilogue(const GemmParams& p, const f32x4 
         for (int e = 0; e < 4; ++e) v[e] = p.alpha * acc[i][e][r];
       }
       float* c = p.C + static_cast<int64_t>(row) * p.ldc + col;
-      if (whole) {
-        float4 out = make_float4(v[0], v[1], v[2], v[3]);
-        if (p.beta != 0.0f) {
-          const float4 old = have_old ? c_old[i][r] : *reinterpret_cast<const float4*>(c);
-          out = make_float4(p.beta * old.x + v[0], p.beta * old.y + v[1], p.beta * old.z + v[2], p.beta * old.w + v[3]);
-        }
-        *reinterpret_cast<float4*>(c) = out;
-      } else if (row < p.M) {
+      if (row < p.M) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (col + e < p.N) c[e] = p.beta == 0.0f ? v[e] : p.beta * c[e] + v[e];
@@ -500,7 +529,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams& p, unsigned ch
     if (kt + 1 < nk) step(kt + 1, 0, 1);
   }
   const float4 none[4][4] = {};
-  split_epilogue<3>(p, acc, m0, n0, wr, wc, g, j, none, false);
+  split_epilogue<3, false>(p, acc, m0, n0, wr, wc, g, j, none);
 }
 
 template <bool A_KMAJOR>
@@ -739,7 +768,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_planes_kernel(const Gemm
     }
     if (kt < nk) planes_step(kt, nk, ga, gb, gemm_smem, tid, frag_a, acc, ra1, b0);
   }
-  split_epilogue<2>(p, acc, m0, n0, wr, wc, g, j, c_old, fetch_c);
+  if (fetch_c) {
+    split_epilogue<2, true>(p, acc, m0, n0, wr, wc, g, j, c_old);
+  } else {
+    split_epilogue<2, false>(p, acc, m0, n0, wr, wc, g, j, c_old);
+  }
 }
 
 // Largest magnitudes for the two-term path, as float32 bit patterns (which order like the magnitudes; a NaN sorts
