@@ -1262,6 +1262,16 @@ __device__ __forceinline__ void pair_multiply(const unsigned char* img_a, const 
   float unused, back_b[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) half_scale_of(amax_b[64 * wc + 4 * j + e], unused, back_b[e]);
+  // (the values of C that are accumulated into are all requested first: read one by one between the stores, each read
+  // would wait for the store before it)
+  float4 old[2][4];
+  if (beta != 0.0f) {  // uniform
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        old[i][r] = *reinterpret_cast<const float4*>(C + (64 * wr + 16 * g + 4 * r + 2 * hh + i) * ldc + 64 * wc + 4 * j);
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1271,12 +1281,10 @@ __device__ __forceinline__ void pair_multiply(const unsigned char* img_a, const 
       half_scale_of(amax_a[row], unused, back_a);
       float4 out = make_float4(alpha * ((acc[i][0][r] * back_a) * back_b[0]), alpha * ((acc[i][1][r] * back_a) * back_b[1]),
                                alpha * ((acc[i][2][r] * back_a) * back_b[2]), alpha * ((acc[i][3][r] * back_a) * back_b[3]));
-      float* c = C + row * ldc + col;
-      if (beta != 0.0f) {
-        const float4 old = *reinterpret_cast<const float4*>(c);
-        out = make_float4(beta * old.x + out.x, beta * old.y + out.y, beta * old.z + out.z, beta * old.w + out.w);
-      }
-      *reinterpret_cast<float4*>(c) = out;
+      if (beta != 0.0f)
+        out = make_float4(beta * old[i][r].x + out.x, beta * old[i][r].y + out.y, beta * old[i][r].z + out.z,
+                          beta * old[i][r].w + out.w);
+      *reinterpret_cast<float4*>(C + row * ldc + col) = out;
     }
 }
 
